@@ -1,0 +1,862 @@
+/*
+ * hnsw_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the arithmetic and graph control flow of the
+ * HNSW hot path of maropu/pgvector-rx (reference, Rust).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * file's library; the product (pgvector-rx_amd/) never links, imports or
+ * falls back to it.
+ *
+ * Parity pinning: the distance functions and graph functions below are
+ * checked in tests/test_oracle_golden.py against every known-answer test,
+ * pure-Rust unit test and pg_regress expected ordering the reference holds
+ * for this path (tests/golden/reference_known_answers.json lists each with
+ * its file:line).  Two inputs are NOT pinned by any reference fixture and
+ * are restated from the published Rust std algorithm:
+ *   - std::collections::BinaryHeap push/pop sift order (tie order among
+ *     equal distances)                                   -> "tie-order parity unpinned"
+ *   - rand::random level draws (the oracle takes explicit levels instead)
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ * -ffp-contract=off matters: rustc never fuses a*b+c.
+ *
+ * Summation orders ("order" argument):
+ *   ORC_ORDER_SEQ  = the reference's order: one f32 accumulator, index order
+ *                    (src/types/vector.rs:518-567, halfvec.rs:687-733).
+ *   ORC_ORDER_W64  = the device's canonical order (DESIGN.md "canonical
+ *                    summation order"): 64 lane partials, lane l owning
+ *                    elements c*64*V + l*V + t (V = 16 bytes / elem size),
+ *                    accumulated in increasing (c,t); then an xor butterfly
+ *                    32,16,8,4,2,1.  Lets tests demand BIT-EXACT equality
+ *                    between the HIP kernels and this file.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+enum { ORC_F32 = 0, ORC_F16 = 1, ORC_BIT = 2 };
+enum { ORC_L2SQ = 0, ORC_NEG_IP = 1, ORC_L1 = 2, ORC_HAMMING = 3, ORC_JACCARD = 4 };
+enum { ORC_ORDER_SEQ = 0, ORC_ORDER_W64 = 1 };
+enum { ORC_ITER_OFF = 0, ORC_ITER_RELAXED = 1, ORC_ITER_STRICT = 2 };
+
+#define HNSW_HEAPTIDS 10 /* src/hnsw_constants.rs:85 */
+
+/* ------------------------------------------------------------------ */
+/* half <-> float, restating src/types/halfvec.rs:54-87 and :92-143    */
+/* ------------------------------------------------------------------ */
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+ORC_API float orc_half_to_f32(uint16_t h)
+{
+    uint32_t sign = (h >> 15) & 1u, exp = (h >> 10) & 0x1fu, mant = h & 0x3ffu;
+    if (exp == 0) {
+        if (mant == 0) return bits_f32(sign << 31);
+        /* denormal: shift the mantissa up until the hidden bit appears */
+        int e = -14;
+        while ((mant & 0x400u) == 0) { mant <<= 1; e -= 1; }
+        mant &= 0x3ffu;
+        return bits_f32((sign << 31) | ((uint32_t)(e + 127) << 23) | (mant << 13));
+    }
+    if (exp == 31) return bits_f32((sign << 31) | (0xffu << 23) | (mant << 13));
+    return bits_f32((sign << 31) | ((exp - 15 + 127) << 23) | (mant << 13));
+}
+
+ORC_API uint16_t orc_f32_to_half(float f)
+{
+    uint32_t bits = f32_bits(f);
+    uint16_t sign = (uint16_t)((bits >> 31) & 1u);
+    int exp = (int)((bits >> 23) & 0xffu);
+    uint32_t mant = bits & 0x7fffffu;
+    if (exp == 0xff) {
+        if (mant == 0) return (uint16_t)((sign << 15) | (0x1f << 10));
+        uint16_t m = (uint16_t)(mant >> 13);
+        if (m < 1) m = 1;
+        return (uint16_t)((sign << 15) | (0x1f << 10) | m);
+    }
+    if (exp > 142) return (uint16_t)((sign << 15) | (0x1f << 10));
+    if (exp < 103) return (uint16_t)(sign << 15);
+    if (exp < 113) {
+        int shift = 113 - exp;
+        uint32_t full = mant | 0x800000u;
+        uint32_t m = full >> (shift + 13);
+        uint32_t round_bit = (full >> (shift + 12)) & 1u;
+        int sticky = (full & ((1u << (shift + 12)) - 1u)) != 0;
+        uint16_t r = (uint16_t)((sign << 15) | (uint16_t)m);
+        if (round_bit && (sticky || (m & 1u))) r = (uint16_t)(r + 1);
+        return r;
+    }
+    {
+        uint16_t half_exp = (uint16_t)((exp - 127 + 15) & 0x1f);
+        uint16_t half_mant = (uint16_t)(mant >> 13);
+        uint32_t round_bit = (mant >> 12) & 1u;
+        uint32_t sticky = mant & 0xfffu;
+        uint16_t r = (uint16_t)((sign << 15) | (half_exp << 10) | half_mant);
+        if (round_bit && (sticky || (half_mant & 1u))) r = (uint16_t)(r + 1);
+        return r;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* scalar distance loops                                               */
+/* ------------------------------------------------------------------ */
+enum { T_L2 = 0, T_IP = 1, T_L1 = 2 };
+
+static inline float term(int kind, float a, float b)
+{
+    if (kind == T_L2) { float d = a - b; return d * d; }   /* vector.rs:522-523 */
+    if (kind == T_IP) return a * b;                        /* vector.rs:534     */
+    return fabsf(a - b);                                   /* vector.rs:564     */
+}
+
+static inline float elem_f32(const void *p, int dtype, int i)
+{
+    if (dtype == ORC_F32) return ((const float *)p)[i];
+    return orc_half_to_f32(((const uint16_t *)p)[i]);      /* halfvec.rs:692 */
+}
+
+/* reference order: single f32 accumulator in index order */
+static float acc_seq(int kind, int dtype, int dim, const void *a, const void *b)
+{
+    float acc = 0.0f;
+    for (int i = 0; i < dim; i++) acc += term(kind, elem_f32(a, dtype, i), elem_f32(b, dtype, i));
+    return acc;
+}
+
+/* device canonical order (see header) */
+static float acc_w64(int kind, int dtype, int dim, const void *a, const void *b)
+{
+    const int V = (dtype == ORC_F32) ? 4 : 8;
+    float p[64], t[64];
+    for (int l = 0; l < 64; l++) {
+        float acc = 0.0f;
+        for (int base = l * V; base < dim; base += 64 * V)
+            for (int k = 0; k < V && base + k < dim; k++)
+                acc = acc + term(kind, elem_f32(a, dtype, base + k), elem_f32(b, dtype, base + k));
+        p[l] = acc;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = p[l] + p[l ^ off];
+        memcpy(p, t, sizeof p);
+    }
+    return p[0];
+}
+
+static inline float acc_f(int kind, int dtype, int dim, const void *a, const void *b, int order)
+{
+    return order == ORC_ORDER_SEQ ? acc_seq(kind, dtype, dim, a, b) : acc_w64(kind, dtype, dim, a, b);
+}
+
+static const uint8_t *popcnt_table(void)
+{   /* PostgreSQL's pg_number_of_ones[256] (used at bitvec.rs:102) is the 8-bit popcount */
+    static uint8_t tab[256]; static int init = 0;
+    if (!init) { for (int i = 0; i < 256; i++) { int c = 0; for (int b = 0; b < 8; b++) c += (i >> b) & 1; tab[i] = (uint8_t)c; } init = 1; }
+    return tab;
+}
+
+/* bitvec.rs:97-106 */
+ORC_API uint64_t orc_hamming(const uint8_t *a, const uint8_t *b, int nbytes)
+{
+    const uint8_t *tab = popcnt_table(); uint64_t d = 0;
+    for (int i = 0; i < nbytes; i++) d += tab[a[i] ^ b[i]];
+    return d;
+}
+
+/* bitvec.rs:113-132 */
+ORC_API double orc_jaccard(const uint8_t *a, const uint8_t *b, int nbytes)
+{
+    const uint8_t *tab = popcnt_table(); uint64_t ab = 0, aa = 0, bb = 0;
+    for (int i = 0; i < nbytes; i++) { ab += tab[a[i] & b[i]]; aa += tab[a[i]]; bb += tab[b[i]]; }
+    if (ab == 0) return 1.0;
+    return 1.0 - ((double)ab / (double)(aa + bb - ab));
+}
+
+static inline int bit_nbytes(int dim) { return (dim + 7) / 8; }
+
+/*
+ * The opclass support function 1 ("distance proc"), f64 result:
+ *   vector_l2_squared_distance vector.rs:598-607, vector_negative_inner_product :624-633,
+ *   l1_distance :652-659; halfvec.rs:765-817; bitvec.rs:144-167.
+ */
+ORC_API double orc_distance(int dtype, int metric, int dim, const void *a, const void *b, int order)
+{
+    switch (metric) {
+    case ORC_L2SQ:   return (double)acc_f(T_L2, dtype, dim, a, b, order);
+    case ORC_NEG_IP: return -(double)acc_f(T_IP, dtype, dim, a, b, order);
+    case ORC_L1:     return (double)acc_f(T_L1, dtype, dim, a, b, order);
+    case ORC_HAMMING:return (double)orc_hamming(a, b, bit_nbytes(dim));
+    case ORC_JACCARD:return orc_jaccard(a, b, bit_nbytes(dim));
+    }
+    return NAN;
+}
+
+/* The SQL-level helpers that exist only for the known-answer tests. */
+ORC_API double orc_l2_distance(int dtype, int dim, const void *a, const void *b)   /* vector.rs:586-593 */
+{ return sqrt((double)acc_seq(T_L2, dtype, dim, a, b)); }
+ORC_API double orc_inner_product(int dtype, int dim, const void *a, const void *b) /* vector.rs:612-619 */
+{ return (double)acc_seq(T_IP, dtype, dim, a, b); }
+ORC_API double orc_cosine_distance(int dtype, int dim, const void *a, const void *b)
+{   /* vector.rs:541-556 + :638-647 */
+    float s = 0.0f, na = 0.0f, nb = 0.0f;
+    for (int i = 0; i < dim; i++) {
+        float ai = elem_f32(a, dtype, i), bi = elem_f32(b, dtype, i);
+        s += ai * bi; na += ai * ai; nb += bi * bi;
+    }
+    double sim = (double)s / sqrt((double)na * (double)nb);
+    if (sim < -1.0) sim = -1.0; if (sim > 1.0) sim = 1.0;   /* f64::clamp; NaN stays NaN */
+    return 1.0 - sim;
+}
+
+/* vector_norm vector.rs:672-683 (f64 accumulator) */
+ORC_API double orc_norm(int dtype, int dim, const void *a)
+{
+    double n = 0.0;
+    for (int i = 0; i < dim; i++) { double v = (double)elem_f32(a, dtype, i); n += v * v; }
+    return sqrt(n);
+}
+
+/* l2_normalize_raw vector.rs:106-126 / halfvec.rs:204-233.  Returns the norm; out is zero-filled when norm==0. */
+ORC_API double orc_l2_normalize(int dtype, int dim, const void *in, void *out)
+{
+    double norm = orc_norm(dtype, dim, in);
+    if (dtype == ORC_F32) {
+        float *o = out; const float *x = in;
+        for (int i = 0; i < dim; i++) o[i] = norm > 0.0 ? (float)((double)x[i] / norm) : 0.0f;
+    } else {
+        uint16_t *o = out; const uint16_t *x = in;
+        for (int i = 0; i < dim; i++)
+            o[i] = norm > 0.0 ? orc_f32_to_half((float)((double)orc_half_to_f32(x[i]) / norm)) : 0;
+    }
+    return norm;
+}
+
+/* ------------------------------------------------------------------ */
+/* Rust std BinaryHeap restated (max-heap on a caller-chosen ordering) */
+/* "tie-order parity unpinned" -- see header.                          */
+/* ------------------------------------------------------------------ */
+typedef struct { double dist; int idx; } hitem;
+typedef struct { hitem *d; int len, cap; int nearest; } heap_t;
+
+/* Ord::cmp of NearestCandidate / FurthestCandidate: graph/mod.rs:103-112,131-139; scan.rs:86-116.
+ * partial_cmp(..).unwrap_or(Equal): NaN compares Equal. */
+static inline int hcmp(const heap_t *h, const hitem *a, const hitem *b)
+{
+    double x = h->nearest ? b->dist : a->dist, y = h->nearest ? a->dist : b->dist;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+static inline int hle(const heap_t *h, const hitem *a, const hitem *b) { return hcmp(h, a, b) <= 0; }
+
+static void heap_init(heap_t *h, int nearest) { h->d = NULL; h->len = h->cap = 0; h->nearest = nearest; }
+static void heap_free(heap_t *h) { free(h->d); h->d = NULL; h->len = h->cap = 0; }
+
+static int heap_sift_up(heap_t *h, int start, int pos)
+{
+    hitem e = h->d[pos];
+    while (pos > start) {
+        int parent = (pos - 1) / 2;
+        if (hle(h, &e, &h->d[parent])) break;
+        h->d[pos] = h->d[parent]; pos = parent;
+    }
+    h->d[pos] = e;
+    return pos;
+}
+static void heap_push(heap_t *h, hitem it)
+{
+    if (h->len == h->cap) { h->cap = h->cap ? h->cap * 2 : 64; h->d = realloc(h->d, (size_t)h->cap * sizeof(hitem)); }
+    h->d[h->len] = it; h->len++;
+    heap_sift_up(h, 0, h->len - 1);
+}
+static void heap_sift_down_to_bottom(heap_t *h, int pos)
+{
+    int end = h->len, start = pos;
+    hitem e = h->d[pos];
+    int child = 2 * pos + 1;
+    int lim = end >= 2 ? end - 2 : 0;               /* end.saturating_sub(2) */
+    while (child <= lim && end >= 2) {
+        if (hle(h, &h->d[child], &h->d[child + 1])) child += 1;
+        h->d[pos] = h->d[child]; pos = child; child = 2 * pos + 1;
+    }
+    if (child == end - 1) { h->d[pos] = h->d[child]; pos = child; }
+    h->d[pos] = e;
+    heap_sift_up(h, start, pos);
+}
+static int heap_pop(heap_t *h, hitem *out)
+{
+    if (h->len == 0) return 0;
+    hitem item = h->d[--h->len];
+    if (h->len > 0) { hitem t = h->d[0]; h->d[0] = item; item = t; heap_sift_down_to_bottom(h, 0); }
+    *out = item;
+    return 1;
+}
+
+/* stable merge sort of hitem by distance (Rust slice::sort_by is stable);
+ * desc=0: a.partial_cmp(b) ascending (graph/mod.rs:249-253, :478-482)
+ * desc=1: b.partial_cmp(a)           (scan.rs:441-446) */
+static void stable_sort(hitem *v, int n, int desc)
+{
+    if (n < 2) return;
+    hitem *tmp = malloc((size_t)n * sizeof(hitem));
+    for (int w = 1; w < n; w *= 2) {
+        for (int lo = 0; lo < n; lo += 2 * w) {
+            int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                /* take right only if right is strictly "less" than left */
+                int right_less = desc ? (v[j].dist > v[i].dist) : (v[j].dist < v[i].dist);
+                tmp[k++] = right_less ? v[j++] : v[i++];
+            }
+            while (i < mid) tmp[k++] = v[i++];
+            while (j < hi) tmp[k++] = v[j++];
+        }
+        memcpy(v, tmp, (size_t)n * sizeof(hitem));
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ */
+/* in-memory graph (graph/mod.rs:12-84) + build state (build.rs:238-285) */
+/* ------------------------------------------------------------------ */
+typedef struct { float distance; int idx; } cand_t;          /* graph/mod.rs:16-22 */
+typedef struct {
+    int level;
+    int *ncnt;         /* [level+1] */
+    cand_t **nbr;      /* [level+1][lm] */
+    int64_t tids[HNSW_HEAPTIDS]; int ntids;
+    int merged;        /* batch schedule only: row tombstoned as a duplicate of another element */
+} elem_t;
+
+typedef struct orc_index {
+    int dtype, metric, dim, m, efc, order, max_level;
+    size_t row_bytes;
+    uint8_t *values; elem_t *el; int n, cap;
+    int entry;                       /* -1 = none (build.rs:255 Option<usize>) */
+    int *vis; int vis_epoch, vis_cap;/* visited "set" */
+    uint64_t cnt[8];                 /* distance evaluations: [0] entry, [1] search loop, [2] select in find, [3] back-link prune, [4] scan */
+    double ind_tuples;
+} orc_index;
+
+static inline int layer_m(int m, int layer) { return layer == 0 ? 2 * m : m; }   /* hnsw_constants.rs:122-128 */
+
+/* types/hnsw.rs:337-349 with BLCKSZ 8192, MAXALIGN'd page header 24, opaque 8, neighbour tuple header 4, ItemId 4, TID 6 */
+ORC_API int orc_max_level(int m)
+{
+    int available = 8192 - 24 - 8 - 4 - 4;
+    int v = available / 6 / m - 2;
+    return v < 255 ? v : 255;
+}
+/* build.rs:373-377 given the uniform draw u */
+ORC_API int orc_level_from_uniform(double u, int m)
+{
+    double r = u > DBL_MIN ? u : DBL_MIN;           /* .max(f64::MIN_POSITIVE) */
+    double ml = 1.0 / log((double)m);               /* hnsw_constants.rs:132-134 */
+    double lv = floor(-log(r) * ml);
+    int mx = orc_max_level(m);
+    return lv < (double)mx ? (int)lv : mx;
+}
+
+ORC_API size_t orc_row_bytes(int dtype, int dim)
+{
+    return dtype == ORC_F32 ? (size_t)dim * 4 : dtype == ORC_F16 ? (size_t)dim * 2 : (size_t)bit_nbytes(dim);
+}
+
+ORC_API orc_index *orc_index_new(int dtype, int metric, int dim, int m, int efc, int order)
+{
+    orc_index *x = calloc(1, sizeof *x);
+    x->dtype = dtype; x->metric = metric; x->dim = dim; x->m = m; x->efc = efc; x->order = order;
+    x->max_level = orc_max_level(m);
+    x->row_bytes = orc_row_bytes(dtype, dim);
+    x->entry = -1;
+    return x;
+}
+
+static void elem_free(elem_t *e)
+{
+    if (e->nbr) for (int l = 0; l <= e->level; l++) free(e->nbr[l]);
+    free(e->nbr); free(e->ncnt); e->nbr = NULL; e->ncnt = NULL;
+}
+ORC_API void orc_index_free(orc_index *x)
+{
+    if (!x) return;
+    for (int i = 0; i < x->n; i++) elem_free(&x->el[i]);
+    free(x->el); free(x->values); free(x->vis); free(x);
+}
+
+static inline const void *rowp(const orc_index *x, int i) { return x->values + (size_t)i * x->row_bytes; }
+
+/* HnswBuildState::distance_fn build.rs:346-369: f64 result truncated to f32 */
+static inline float dist_build(orc_index *x, const void *a, const void *b, int counter)
+{
+    x->cnt[counter]++;
+    return (float)orc_distance(x->dtype, x->metric, x->dim, a, b, x->order);
+}
+
+static void vis_begin(orc_index *x)
+{
+    if (x->vis_cap < x->cap) { x->vis = realloc(x->vis, (size_t)x->cap * sizeof(int)); memset(x->vis + x->vis_cap, 0, (size_t)(x->cap - x->vis_cap) * sizeof(int)); x->vis_cap = x->cap; }
+    x->vis_epoch++;
+    if (x->vis_epoch == 0x7fffffff) { memset(x->vis, 0, (size_t)x->vis_cap * sizeof(int)); x->vis_epoch = 1; }
+}
+static inline int vis_test_set(orc_index *x, int i) { if (x->vis[i] == x->vis_epoch) return 1; x->vis[i] = x->vis_epoch; return 0; }
+
+/* graph/mod.rs:161-255.  ep/out are (distance f32, idx); returns count, nearest first. */
+static int search_layer(orc_index *x, const cand_t *ep, int nep, int ef, int layer, const void *q, cand_t *out)
+{
+    heap_t C, W; heap_init(&C, 1); heap_init(&W, 0);
+    int result_len = 0;
+    vis_begin(x);
+    for (int i = 0; i < nep; i++) {
+        vis_test_set(x, ep[i].idx);
+        hitem it = { (double)ep[i].distance, ep[i].idx };
+        heap_push(&C, it); heap_push(&W, it); result_len++;
+    }
+    hitem c;
+    while (heap_pop(&C, &c)) {
+        float f_dist = W.len ? (float)W.d[0].dist : FLT_MAX;
+        if ((float)c.dist > f_dist) break;
+        elem_t *ce = &x->el[c.idx];
+        if (ce->level < layer) continue;
+        int cn = ce->ncnt[layer];
+        for (int k = 0; k < cn; k++) {
+            int e = ce->nbr[layer][k].idx;
+            if (vis_test_set(x, e)) continue;
+            if (x->el[e].level < layer) continue;
+            float ed = dist_build(x, q, rowp(x, e), 1);
+            int always_add = result_len < ef;
+            f_dist = W.len ? (float)W.d[0].dist : FLT_MAX;
+            if (ed < f_dist || always_add) {
+                hitem it = { (double)ed, e };
+                heap_push(&C, it); heap_push(&W, it); result_len++;
+                if (result_len > ef) { hitem drop; heap_pop(&W, &drop); result_len--; }
+            }
+        }
+    }
+    /* results.into_iter() = internal array order, then stable sort ascending */
+    stable_sort(W.d, W.len, 0);
+    int n = W.len;
+    for (int i = 0; i < n; i++) { out[i].distance = (float)W.d[i].dist; out[i].idx = W.d[i].idx; }
+    heap_free(&C); heap_free(&W);
+    return n;
+}
+
+/* graph/mod.rs:315-339 */
+static int check_element_closer(orc_index *x, const cand_t *e, const cand_t *r, int nr, int counter)
+{
+    for (int i = 0; i < nr; i++) {
+        float d = dist_build(x, rowp(x, e->idx), rowp(x, r[i].idx), counter);
+        if (d <= e->distance) return 0;
+    }
+    return 1;
+}
+
+/* graph/mod.rs:269-308; returns count written to out (capacity >= max(ncand, maxn)) */
+static int select_neighbors(orc_index *x, const cand_t *cand, int ncand, int maxn, cand_t *out, int counter)
+{
+    if (ncand <= maxn) { memcpy(out, cand, (size_t)ncand * sizeof(cand_t)); return ncand; }
+    cand_t *disc = malloc((size_t)ncand * sizeof(cand_t)); int nd = 0, nr = 0;
+    for (int i = 0; i < ncand; i++) {
+        if (nr >= maxn) break;
+        if (check_element_closer(x, &cand[i], out, nr, counter)) out[nr++] = cand[i];
+        else disc[nd++] = cand[i];
+    }
+    for (int i = 0; i < nd; i++) { if (nr >= maxn) break; out[nr++] = disc[i]; }
+    free(disc);
+    return nr;
+}
+
+/* graph/mod.rs:355-427 */
+static void find_element_neighbors(orc_index *x, int new_idx, int entry_idx)
+{
+    elem_t *ne = &x->el[new_idx];
+    const void *q = rowp(x, new_idx);
+    int new_level = ne->level, entry_level = x->el[entry_idx].level;
+    int cap = x->efc > 1 ? x->efc : 1;
+    cand_t *ep = malloc((size_t)(cap + 1) * sizeof(cand_t)), *w = malloc((size_t)(cap + 1) * sizeof(cand_t));
+    cand_t *sel = malloc((size_t)(cap + 2 * x->m + 1) * sizeof(cand_t));
+    int nep = 1;
+    ep[0].distance = dist_build(x, q, rowp(x, entry_idx), 0); ep[0].idx = entry_idx;
+
+    for (int lc = entry_level; lc >= new_level + 1; lc--) {
+        int nw = search_layer(x, ep, nep, 1, lc, q, w);
+        if (nw > 0) { ep[0] = w[0]; nep = 1; }
+    }
+    int start = new_level < entry_level ? new_level : entry_level;
+    for (int lc = start; lc >= 0; lc--) {
+        int lm = layer_m(x->m, lc);
+        int nw = search_layer(x, ep, nep, x->efc, lc, q, w);
+        int ns = select_neighbors(x, w, nw, lm, sel, 2);
+        memcpy(ne->nbr[lc], sel, (size_t)ns * sizeof(cand_t)); ne->ncnt[lc] = ns;
+        memcpy(ep, w, (size_t)nw * sizeof(cand_t)); nep = nw;          /* mod.rs:425: whole W */
+    }
+    free(ep); free(w); free(sel);
+}
+
+/* graph/mod.rs:442-489 */
+static void update_neighbor_connections(orc_index *x, int new_idx)
+{
+    elem_t *ne = &x->el[new_idx];
+    for (int lc = ne->level; lc >= 0; lc--) {
+        int lm = layer_m(x->m, lc);
+        int ns = ne->ncnt[lc];
+        cand_t *snap = malloc((size_t)(ns + 1) * sizeof(cand_t));
+        memcpy(snap, ne->nbr[lc], (size_t)ns * sizeof(cand_t));
+        for (int k = 0; k < ns; k++) {
+            elem_t *nb = &x->el[snap[k].idx];
+            cand_t nc = { snap[k].distance, new_idx };
+            if (nb->ncnt[lc] < lm) { nb->nbr[lc][nb->ncnt[lc]++] = nc; continue; }
+            int tot = nb->ncnt[lc] + 1;
+            hitem *all = malloc((size_t)tot * sizeof(hitem));
+            for (int i = 0; i < tot - 1; i++) { all[i].dist = (double)nb->nbr[lc][i].distance; all[i].idx = nb->nbr[lc][i].idx; }
+            all[tot - 1].dist = (double)nc.distance; all[tot - 1].idx = nc.idx;
+            stable_sort(all, tot, 0);
+            cand_t *allc = malloc((size_t)tot * sizeof(cand_t)), *sel = malloc((size_t)tot * sizeof(cand_t));
+            for (int i = 0; i < tot; i++) { allc[i].distance = (float)all[i].dist; allc[i].idx = all[i].idx; }
+            int nsel = select_neighbors(x, allc, tot, lm, sel, 3);
+            memcpy(nb->nbr[lc], sel, (size_t)nsel * sizeof(cand_t)); nb->ncnt[lc] = nsel;
+            free(all); free(allc); free(sel);
+        }
+        free(snap);
+    }
+}
+
+static int push_element(orc_index *x, const void *row, int level)
+{
+    if (x->n == x->cap) {
+        x->cap = x->cap ? x->cap * 2 : 1024;
+        x->el = realloc(x->el, (size_t)x->cap * sizeof(elem_t));
+        x->values = realloc(x->values, (size_t)x->cap * x->row_bytes);
+    }
+    int idx = x->n++;
+    memcpy(x->values + (size_t)idx * x->row_bytes, row, x->row_bytes);
+    elem_t *e = &x->el[idx];
+    memset(e, 0, sizeof *e);
+    e->level = level;
+    e->ncnt = calloc((size_t)level + 1, sizeof(int));
+    e->nbr = calloc((size_t)level + 1, sizeof(cand_t *));
+    for (int l = 0; l <= level; l++) e->nbr[l] = calloc((size_t)layer_m(x->m, l), sizeof(cand_t)); /* mod.rs:71-83 */
+    return idx;
+}
+
+/* duplicate scan of build.rs:482-512; returns the element the row merges into, or -1 */
+static int find_duplicate(orc_index *x, int new_idx)
+{
+    elem_t *ne = &x->el[new_idx];
+    for (int k = 0; k < ne->ncnt[0]; k++) {
+        if (ne->nbr[0][k].distance != 0.0f) break;
+        int d = ne->nbr[0][k].idx;
+        if (memcmp(rowp(x, new_idx), rowp(x, d), x->row_bytes) == 0 && x->el[d].ntids < HNSW_HEAPTIDS) return d;
+    }
+    return -1;
+}
+
+/*
+ * build_callback build.rs:400-535 for one row (the reference's sequential schedule).
+ * `row` must already be normalised for cosine opclasses (orc_l2_normalize; zero-norm rows are
+ * skipped by the caller, build.rs:433-435).  Returns the element index the tid landed in.
+ */
+ORC_API int orc_index_insert(orc_index *x, const void *row, int level, int64_t tid)
+{
+    if (level > x->max_level) level = x->max_level;
+    int new_idx = push_element(x, row, level);
+    if (x->entry >= 0) {
+        int entry_idx = x->entry;
+        find_element_neighbors(x, new_idx, entry_idx);
+        int dup = find_duplicate(x, new_idx);
+        if (dup >= 0) {
+            x->el[dup].tids[x->el[dup].ntids++] = tid;
+            elem_free(&x->el[new_idx]); x->n--;          /* elements.pop(); values.truncate() */
+            x->ind_tuples += 1.0;
+            return dup;
+        }
+        update_neighbor_connections(x, new_idx);
+        if (x->el[new_idx].level > x->el[entry_idx].level) x->entry = new_idx;
+    } else {
+        x->entry = new_idx;
+    }
+    x->el[new_idx].tids[0] = tid; x->el[new_idx].ntids = 1;
+    x->ind_tuples += 1.0;
+    return new_idx;
+}
+
+/*
+ * Snapshot ("lock-step") schedule used by the batched device build: every row of the batch runs
+ * find_element_neighbors against the graph as it stood when the batch began (rows of one batch do
+ * not see each other, and share the entry point of the batch start); then, in row order, the
+ * duplicate merge / back-links / entry-point update of build.rs:482-525 are applied.  A row merged
+ * as a duplicate stays in the arena as a tombstone (merged=1, no links) because later rows of the
+ * batch already hold their indices.  n==1 is exactly orc_index_insert apart from the tombstone.
+ * out_idx[i] = element that holds tid i.
+ */
+ORC_API void orc_index_insert_batch(orc_index *x, const void *rows, const int *levels, const int64_t *tids, int n, int *out_idx)
+{
+    const uint8_t *r = rows;
+    int i0 = 0;
+    if (x->entry < 0 && n > 0) { int e = orc_index_insert(x, r, levels[0], tids[0]); if (out_idx) out_idx[0] = e; i0 = 1; }
+    int first = x->n, entry_idx = x->entry;
+    for (int i = i0; i < n; i++) {
+        int lv = levels[i] > x->max_level ? x->max_level : levels[i];
+        push_element(x, r + (size_t)i * x->row_bytes, lv);
+    }
+    for (int i = i0; i < n; i++) find_element_neighbors(x, first + (i - i0), entry_idx);
+    for (int i = i0; i < n; i++) {
+        int new_idx = first + (i - i0);
+        int dup = find_duplicate(x, new_idx);
+        if (dup >= 0 && !x->el[dup].merged) {
+            x->el[dup].tids[x->el[dup].ntids++] = tids[i];
+            elem_t *e = &x->el[new_idx];
+            for (int l = 0; l <= e->level; l++) e->ncnt[l] = 0;
+            e->merged = 1; e->ntids = 0;
+            x->ind_tuples += 1.0;
+            if (out_idx) out_idx[i] = dup;
+            continue;
+        }
+        update_neighbor_connections(x, new_idx);
+        if (x->el[new_idx].level > x->el[x->entry].level) x->entry = new_idx;
+        x->el[new_idx].tids[0] = tids[i]; x->el[new_idx].ntids = 1;
+        x->ind_tuples += 1.0;
+        if (out_idx) out_idx[i] = new_idx;
+    }
+}
+
+/* ---- accessors used by tests ---- */
+ORC_API int orc_index_size(const orc_index *x) { return x->n; }
+ORC_API int orc_index_entry(const orc_index *x) { return x->entry; }
+ORC_API int orc_index_level(const orc_index *x, int i) { return x->el[i].level; }
+ORC_API int orc_index_merged(const orc_index *x, int i) { return x->el[i].merged; }
+ORC_API int orc_index_ntids(const orc_index *x, int i) { return x->el[i].ntids; }
+ORC_API int64_t orc_index_tid(const orc_index *x, int i, int k) { return x->el[i].tids[k]; }
+ORC_API uint64_t orc_index_counter(const orc_index *x, int k) { return x->cnt[k]; }
+ORC_API void orc_index_reset_counters(orc_index *x) { memset(x->cnt, 0, sizeof x->cnt); }
+ORC_API int orc_index_neighbors(const orc_index *x, int i, int layer, int *ids, float *dist)
+{
+    if (layer > x->el[i].level) return -1;
+    int n = x->el[i].ncnt[layer];
+    for (int k = 0; k < n; k++) { if (ids) ids[k] = x->el[i].nbr[layer][k].idx; if (dist) dist[k] = x->el[i].nbr[layer][k].distance; }
+    return n;
+}
+/* test hook mirroring the hand-built graphs of graph/mod.rs:537-584 */
+ORC_API int orc_index_add_raw(orc_index *x, const void *row, int level) { int i = push_element(x, row, level); if (x->entry < 0) x->entry = i; x->el[i].ntids = 1; x->el[i].tids[0] = i; return i; }
+ORC_API void orc_index_link_raw(orc_index *x, int i, int layer, int j, float d)
+{ elem_t *e = &x->el[i]; e->nbr[layer][e->ncnt[layer]].idx = j; e->nbr[layer][e->ncnt[layer]].distance = d; e->ncnt[layer]++; }
+ORC_API int orc_search_layer_raw(orc_index *x, const void *q, const int *ep_idx, int nep, int ef, int layer, int *ids, float *dist)
+{
+    cand_t *ep = malloc((size_t)nep * sizeof(cand_t)), *out = malloc((size_t)(ef + nep + 1) * sizeof(cand_t));
+    /* stash the query as a temporary row so dist_build sees arena memory, as the reference's tests do (mod.rs:564) */
+    for (int i = 0; i < nep; i++) { ep[i].idx = ep_idx[i]; ep[i].distance = dist_build(x, q, rowp(x, ep_idx[i]), 0); }
+    int n = search_layer(x, ep, nep, ef, layer, q, out);
+    for (int i = 0; i < n; i++) { ids[i] = out[i].idx; dist[i] = out[i].distance; }
+    free(ep); free(out);
+    return n;
+}
+ORC_API int orc_select_neighbors_raw(orc_index *x, const int *cand_idx, const float *cand_dist, int n, int maxn, int *ids)
+{
+    cand_t *c = malloc((size_t)n * sizeof(cand_t)), *o = malloc((size_t)(n + maxn) * sizeof(cand_t));
+    for (int i = 0; i < n; i++) { c[i].idx = cand_idx[i]; c[i].distance = cand_dist[i]; }
+    int k = select_neighbors(x, c, n, maxn, o, 2);
+    for (int i = 0; i < k; i++) ids[i] = o[i].idx;
+    free(c); free(o);
+    return k;
+}
+ORC_API void orc_find_element_neighbors_raw(orc_index *x, int new_idx, int entry_idx) { find_element_neighbors(x, new_idx, entry_idx); }
+ORC_API void orc_update_neighbor_connections_raw(orc_index *x, int new_idx) { update_neighbor_connections(x, new_idx); }
+
+/* ------------------------------------------------------------------ */
+/* scan: in-memory mirror of src/index/scan.rs (rows addressed by element
+ * index instead of (blkno, offno); no deleted tuples, no stale versions) */
+/* ------------------------------------------------------------------ */
+typedef struct orc_scan {
+    orc_index *x; void *q; int q_null;
+    int ef_search, iterative; int64_t max_scan_tuples;
+    hitem *results; int nres, rescap;        /* sorted, nearest LAST (scan.rs:441-446) */
+    heap_t discarded; uint8_t *visited;      /* iterative-scan state (scan.rs:597-612) */
+    int first, iter_init; int64_t tuples; double previous_distance;
+    int cur; int cur_tid_left; double cur_dist;
+} orc_scan;
+
+static inline double dist_scan(orc_scan *s, int e)
+{   /* load_element scan.rs:186-192: NULL query => 0.0 */
+    if (s->q_null) return 0.0;
+    s->x->cnt[4]++;
+    return orc_distance(s->x->dtype, s->x->metric, s->x->dim, s->q, rowp(s->x, e), s->x->order);
+}
+
+/* search_layer_disk scan.rs:302-448.  visited: caller bitmap or NULL (=> local); discarded may be NULL.
+ * Entry points carry their distances.  Output nearest-last in *out (malloc'd), returns count. */
+static int search_layer_scan(orc_scan *s, const hitem *ep, int nep, int ef, int layer,
+                             uint8_t *visited, heap_t *discarded, int add_entry_to_visited, hitem **out)
+{
+    orc_index *x = s->x;
+    uint8_t *local = NULL;
+    if (!visited) { local = calloc((size_t)x->n + 1, 1); visited = local; }
+    heap_t C, W; heap_init(&C, 1); heap_init(&W, 0);
+    int w_len = 0;
+    for (int i = 0; i < nep; i++) {
+        if (add_entry_to_visited) visited[ep[i].idx] = 1;
+        heap_push(&C, ep[i]); heap_push(&W, ep[i]); w_len++;
+    }
+    hitem c;
+    while (heap_pop(&C, &c)) {
+        double f_dist = W.len ? W.d[0].dist : DBL_MAX;
+        if (c.dist > f_dist) { if (discarded) heap_push(discarded, c); break; }
+        elem_t *ce = &x->el[c.idx];
+        if (ce->level < layer) continue;            /* load_neighbor_tids would read beyond the tuple; cannot happen for valid graphs */
+        int cn = ce->ncnt[layer];
+        for (int k = 0; k < cn; k++) {
+            int e = ce->nbr[layer][k].idx;
+            if (visited[e]) continue;
+            visited[e] = 1;
+            int always_add = w_len < ef;
+            f_dist = W.len ? W.d[0].dist : DBL_MAX;
+            double d = dist_scan(s, e);
+            if (!always_add && d >= f_dist) {       /* load_element returned None (scan.rs:195-200) */
+                if (discarded) {                    /* second load, scan.rs:385-404 (costs a 2nd distance) */
+                    double d2 = dist_scan(s, e);
+                    if (x->el[e].level >= layer) { hitem it = { d2, e }; heap_push(discarded, it); }
+                }
+                continue;
+            }
+            if (x->el[e].level < layer) continue;
+            hitem it = { d, e };
+            heap_push(&C, it); heap_push(&W, it); w_len++;
+            if (w_len > ef) { hitem ev; heap_pop(&W, &ev); w_len--; if (discarded) heap_push(discarded, ev); }
+        }
+    }
+    if (discarded) { hitem r; while (heap_pop(&C, &r)) heap_push(discarded, r); }
+    stable_sort(W.d, W.len, 1);
+    int n = W.len;
+    *out = malloc((size_t)(n + 1) * sizeof(hitem));
+    memcpy(*out, W.d, (size_t)n * sizeof(hitem));
+    heap_free(&C); heap_free(&W); free(local);
+    return n;
+}
+
+/* get_scan_items scan.rs:458-530 */
+static void get_scan_items(orc_scan *s, uint8_t *visited, heap_t *discarded)
+{
+    orc_index *x = s->x;
+    s->nres = 0;
+    if (x->entry < 0) return;
+    hitem ep = { dist_scan(s, x->entry), x->entry };
+    int ep_level = x->el[x->entry].level;
+    for (int lc = ep_level; lc >= 1; lc--) {
+        hitem *w; int nw = search_layer_scan(s, &ep, 1, 1, lc, NULL, NULL, 1, &w);
+        if (nw == 0) { free(w); return; }
+        ep = w[nw - 1]; free(w);
+    }
+    hitem *w; int nw = search_layer_scan(s, &ep, 1, s->ef_search, 0, visited, discarded, 1, &w);
+    free(s->results); s->results = w; s->nres = nw; s->rescap = nw + 1;
+}
+
+/* resume_scan_items scan.rs:538-577 */
+static void resume_scan_items(orc_scan *s)
+{
+    s->nres = 0;
+    if (s->discarded.len == 0) return;
+    int bs = s->ef_search, nep = 0;
+    hitem *ep = malloc((size_t)bs * sizeof(hitem));
+    while (nep < bs && s->discarded.len > 0) heap_pop(&s->discarded, &ep[nep++]);
+    hitem *w; int nw = search_layer_scan(s, ep, nep, bs, 0, s->visited, &s->discarded, 0, &w);
+    free(ep); free(s->results); s->results = w; s->nres = nw; s->rescap = nw + 1;
+}
+
+ORC_API orc_scan *orc_scan_begin(orc_index *x, const void *query, int ef_search, int iterative, int64_t max_scan_tuples)
+{
+    orc_scan *s = calloc(1, sizeof *s);
+    s->x = x; s->ef_search = ef_search; s->iterative = iterative; s->max_scan_tuples = max_scan_tuples;
+    s->q_null = query == NULL;
+    if (query) { s->q = malloc(x->row_bytes); memcpy(s->q, query, x->row_bytes); }
+    heap_init(&s->discarded, 1);
+    s->first = 1; s->cur = -1; s->previous_distance = -INFINITY;   /* scan.rs:661 f64::NEG_INFINITY */
+    return s;
+}
+ORC_API void orc_scan_end(orc_scan *s)
+{ if (!s) return; free(s->q); free(s->results); heap_free(&s->discarded); free(s->visited); free(s); }
+
+/* amgettuple scan.rs:709-876.  Returns 1 and fills tid/dist/elem, or 0 when exhausted. */
+ORC_API int orc_scan_next(orc_scan *s, int64_t *tid, double *dist, int *elem)
+{
+    orc_index *x = s->x;
+    if (s->first) {
+        int use_iter = s->iterative != ORC_ITER_OFF;
+        if (use_iter) { s->visited = calloc((size_t)x->n + 1, 1); get_scan_items(s, s->visited, &s->discarded); }
+        else get_scan_items(s, NULL, NULL);
+        s->iter_init = use_iter;                     /* scan.rs:789 */
+        s->first = 0;
+    }
+    for (;;) {
+        if (s->cur >= 0) {
+            if (s->cur_tid_left > 0) {
+                int64_t t = x->el[s->cur].tids[--s->cur_tid_left];    /* heaptids.pop() */
+                if (s->iterative == ORC_ITER_STRICT) {
+                    if (s->cur_dist < s->previous_distance) continue;
+                    s->previous_distance = s->cur_dist;
+                }
+                if (tid) *tid = t; if (dist) *dist = s->cur_dist; if (elem) *elem = s->cur;
+                return 1;
+            }
+            s->cur = -1;
+        }
+        if (s->nres == 0) {
+            if (s->iterative == ORC_ITER_OFF) return 0;
+            if (!s->iter_init) return 0;
+            if (s->tuples >= s->max_scan_tuples) {
+                if (s->discarded.len == 0) return 0;
+                hitem sc; heap_pop(&s->discarded, &sc);
+                if (s->rescap < 1) { s->results = realloc(s->results, 4 * sizeof(hitem)); s->rescap = 4; }
+                s->results[0] = sc; s->nres = 1;
+            } else {
+                resume_scan_items(s);
+            }
+            if (s->nres == 0) return 0;
+        }
+        hitem sc = s->results[--s->nres];
+        if (x->el[sc.idx].ntids == 0) continue;
+        s->tuples++;
+        s->cur = sc.idx; s->cur_tid_left = x->el[sc.idx].ntids; s->cur_dist = sc.dist;
+    }
+}
+
+/* convenience: non-iterative top-k of one query -> element ids + f64 distances; returns count */
+ORC_API int orc_search_topk(orc_index *x, const void *query, int ef_search, int k, int *ids, double *dist)
+{
+    orc_scan *s = orc_scan_begin(x, query, ef_search, ORC_ITER_OFF, 0);
+    int n = 0, e; double d; int64_t t;
+    while (n < k && orc_scan_next(s, &t, &d, &e)) { ids[n] = e; dist[n] = d; n++; }
+    orc_scan_end(s);
+    return n;
+}
+
+/* exact brute force top-k (ground truth for recall; distances in the index's order) */
+ORC_API int orc_bruteforce_topk(orc_index *x, const void *query, int k, int *ids, double *dist)
+{
+    int n = 0;
+    for (int i = 0; i < x->n; i++) {
+        if (x->el[i].merged) continue;
+        double d = orc_distance(x->dtype, x->metric, x->dim, query, rowp(x, i), x->order);
+        if (n == k && !(d < dist[k - 1])) continue;
+        int p = n < k ? n++ : k - 1;
+        while (p > 0 && d < dist[p - 1]) { dist[p] = dist[p - 1]; ids[p] = ids[p - 1]; p--; }
+        dist[p] = d; ids[p] = i;
+    }
+    return n;
+}
+
+/* bulk helpers so Python tests stay fast */
+ORC_API void orc_distances_many(int dtype, int metric, int dim, const void *q, const void *rows, const int32_t *ids, int n, int order, double *out)
+{
+    size_t rb = orc_row_bytes(dtype, dim);
+    for (int i = 0; i < n; i++) {
+        const uint8_t *r = (const uint8_t *)rows + (size_t)(ids ? ids[i] : i) * rb;
+        out[i] = orc_distance(dtype, metric, dim, q, r, order);
+    }
+}
+ORC_API void orc_pairwise(int dtype, int metric, int dim, const void *rows, const int32_t *ids, int w, int order, double *out)
+{
+    size_t rb = orc_row_bytes(dtype, dim);
+    for (int i = 0; i < w; i++) for (int j = 0; j < w; j++)
+        out[(size_t)i * w + j] = orc_distance(dtype, metric, dim, (const uint8_t *)rows + (size_t)ids[i] * rb,
+                                              (const uint8_t *)rows + (size_t)ids[j] * rb, order);
+}
