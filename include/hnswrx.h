@@ -1,0 +1,192 @@
+/*
+ * hnswrx.h -- C ABI of the MI355X-native HNSW distance engine for pgvector-rx.
+ *
+ * This is the drop-in boundary for ONE path of the reference (maropu/pgvector-rx): the distance
+ * evaluations inside HNSW search-layer candidate expansion and the ef_construction neighbour-selection
+ * loop of index build.  A Rust/pgrx host binds these symbols with an `extern "C"` block
+ * (INTEGRATION.md shows it) in place of the per-pair fmgr trampoline; everything PostgreSQL-side
+ * (access-method handler, operator classes, pages, WAL) stays in the host.
+ *
+ * Conventions
+ *   - plain C, POD arguments only; no exceptions/longjmp/abort cross the boundary.
+ *   - every entry returns int: 0 = ok, <0 = HX_E_*; hx_last_error() gives the text
+ *     (the host turns non-zero into pgrx::error!, mirroring ereport(ERROR) -- build.rs:399, scan.rs:708).
+ *   - a handle owns one HIP stream and is NOT thread-safe (the reference is one single-threaded backend
+ *     per connection, build.rs:385); host pointers are never retained after a call returns.
+ *   - distances come back as f32: the build path consumes `f64 as f32` (build.rs:366-367) and the scan
+ *     path's f64 (scan.rs:190-191) is a widening of the same f32 accumulator, so f32 is lossless for
+ *     L2/IP/L1/Hamming.  Jaccard is computed in f64 on the device and rounded once to f32.
+ *   - rows are dense payloads WITHOUT the varlena header: dim f32 (vector.rs:43-48 `x[dim]`),
+ *     dim u16 IEEE binary16 (halfvec.rs:41-46), or ceil(dim/8) bytes MSB-first (bitvec.rs:28-37).
+ *   - row ids are dense uint32 in append order (the host keeps the TID <-> row-id map).
+ */
+#ifndef HNSWRX_H
+#define HNSWRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HX_ABI_VERSION 1
+
+/* element type of the indexed column */
+enum hx_dtype { HX_F32 = 0 /* vector */, HX_F16 = 1 /* halfvec */, HX_BIT = 2 /* bit(n) */ };
+
+/* which opclass support FUNCTION 1 the index names (hnsw_constants.rs:12) */
+enum hx_metric {
+    HX_L2SQ = 0,    /* vector_l2_squared_distance  vector.rs:598-607, halfvec.rs:780-791 */
+    HX_NEG_IP = 1,  /* vector_negative_inner_product vector.rs:624-633; also the cosine opclasses (rows pre-normalised, vector.rs:852-856) */
+    HX_L1 = 2,      /* l1_distance                 vector.rs:652-659 */
+    HX_HAMMING = 3, /* hamming_distance            bitvec.rs:144-153 */
+    HX_JACCARD = 4  /* jaccard_distance            bitvec.rs:156-167 */
+};
+
+enum hx_status {
+    HX_OK = 0,
+    HX_E_ARG = -1,      /* bad argument (null, out of range id, dtype/metric mismatch) */
+    HX_E_DIM = -2,      /* "different vector dimensions" vector.rs:510-514 / max dims hnsw_constants.rs:4 */
+    HX_E_NOMEM = -3,    /* host or device allocation failed / capacity exceeded */
+    HX_E_HIP = -4,      /* a HIP runtime call failed */
+    HX_E_NODEVICE = -5, /* no usable GPU: the engine never falls back to the CPU */
+    HX_E_STATE = -6     /* call sequence error */
+};
+
+typedef struct hx_engine hx_engine;   /* device row store + kernels (replaces DistanceFn, graph/mod.rs:144-145) */
+typedef struct hx_index hx_index;     /* host-side HNSW graph driven in lock-step over the engine (graph/mod.rs, build.rs, scan.rs) */
+
+/* group query source: a row already in the store, or a slot of the uploaded query set */
+#define HX_QUERY_SLOT 0x80000000u
+
+int hx_abi_version(void);
+const char *hx_last_error(const hx_engine *e);     /* e may be NULL: error of the last failed hx_create on this thread */
+
+/* ------------------------------------------------------------------------------------------------
+ * Engine: device-resident row store + batched distance kernels
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Creates an engine on HIP device `device` for rows of `dim` elements; capacity_rows is reserved up
+ * front in HBM (the reference's Vec<u8> arena, build.rs:249, grows instead).  Fails with
+ * HX_E_NODEVICE when no GPU is visible. */
+int hx_create(int device, int dtype, int metric, int dim, uint64_t capacity_rows, hx_engine **out);
+int hx_destroy(hx_engine *e);
+
+int hx_dim(const hx_engine *e);
+uint64_t hx_row_bytes(const hx_engine *e);   /* payload bytes per row as the caller supplies them */
+uint64_t hx_num_rows(const hx_engine *e);
+void *hx_stream(const hx_engine *e);         /* the hipStream_t every kernel of this handle runs on */
+
+/* Appends n rows (host memory, row-major, hx_row_bytes each); *first_row_id = id of the first.
+ * Mirrors bs.values.extend_from_slice, build.rs:451-454. */
+int hx_append_rows(hx_engine *e, const void *rows_host, uint64_t n, uint64_t *first_row_id);
+/* Same, rows already in device memory (synthetic benches keep data in HBM). */
+int hx_append_rows_device(hx_engine *e, const void *rows_dev, uint64_t n, uint64_t *first_row_id);
+/* Drops the last n rows: bs.values.truncate on a duplicate, build.rs:507-509. */
+int hx_pop_rows(hx_engine *e, uint64_t n);
+/* Copies rows back (tests / page serialiser). */
+int hx_read_rows(hx_engine *e, uint64_t first, uint64_t n, void *rows_host);
+
+/* L2-normalises rows [first, first+n) in place with the reference's f64 procedure
+ * (l2_normalize_raw vector.rs:106-126, halfvec.rs:204-233 incl. its f32->half rounding);
+ * norms_host (may be NULL) receives the f64 norms (vector_norm vector.rs:672-683) so the host can
+ * skip zero-norm rows (build.rs:433-435). */
+int hx_normalize_rows(hx_engine *e, uint64_t first, uint64_t n, double *norms_host);
+
+/* Uploads a set of nq query vectors (host memory) into the engine's query slots 0..nq-1;
+ * with normalize!=0 they are normalised first (scan.rs:749-751). */
+int hx_set_queries(hx_engine *e, const void *queries_host, uint32_t nq, int normalize);
+int hx_set_queries_device(hx_engine *e, const void *queries_dev, uint32_t nq, int normalize);
+
+/* One query vector (host) against n rows: the batched form of the <=2M FunctionCall2Coll calls of one
+ * candidate expansion (graph/mod.rs:205-224, scan.rs:362-383).  out[i] = d(query, row_ids[i]). */
+int hx_distances(hx_engine *e, const void *query_host, const uint32_t *row_ids, uint32_t n, float *out);
+
+/* Lock-step form: n_groups expansions in one launch.  Group g evaluates query group_query[g]
+ * (a row id, or HX_QUERY_SLOT|slot) against row_ids[group_offsets[g] .. group_offsets[g+1]);
+ * out is indexed like row_ids. */
+int hx_distances_batch(hx_engine *e, uint32_t n_groups, const uint32_t *group_query,
+                       const uint32_t *group_offsets, const uint32_t *row_ids, float *out);
+
+/* Pairwise distances among w rows: out[i*w + j] = d(ids[i], ids[j]) (symmetric, 0 diagonal is
+ * computed, not assumed).  The operand set of select_neighbors/check_element_closer,
+ * graph/mod.rs:284-297,324-336. */
+int hx_pairwise(hx_engine *e, const uint32_t *ids, uint32_t w, float *out_wxw);
+
+/* Many small pair blocks in one launch (back-link pruning of one insert touches <= lm neighbours, each a
+ * (lm+1)-row block, graph/mod.rs:458-486).  Group g has na[g] "A" rows followed by nb[g] "B" rows in
+ * ids[group_offsets[g]..]:
+ *    nb[g] == 0 : lower triangle of A x A, packed: out[out_offsets[g] + i*(i-1)/2 + j] = d(A_i, A_j), j < i
+ *    nb[g]  > 0 : full rectangle:          out[out_offsets[g] + i*nb + j]      = d(A_i, B_j)
+ * na+nb <= HX_PAIR_MAX_ROWS per group. */
+#define HX_PAIR_MAX_ROWS 64
+int hx_pairwise_many(hx_engine *e, uint32_t n_groups, const uint32_t *group_offsets,
+                     const uint16_t *na, const uint16_t *nb, const uint32_t *ids,
+                     const uint64_t *out_offsets, float *out);
+
+/* Byte equality of row pairs (the datumIsEqual-style duplicate test, build.rs:491-500). */
+int hx_rows_equal(hx_engine *e, uint32_t n_pairs, const uint32_t *a_ids, const uint32_t *b_ids, uint8_t *equal_out);
+
+/* Kernel timing of the last hx_distances_batch / hx_pairwise_many launch on this handle, measured
+ * with HIP events on the handle's stream (bench.py's roofline leg). */
+int hx_set_timing(hx_engine *e, int enabled);
+int hx_last_kernel_ms(hx_engine *e, float *ms);
+/* Accumulated since the last reset, while timing is enabled: kind 0 = query-vs-rows kernel (units =
+ * distances), kind 1 = pair-block kernel (units = pairs). */
+int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index: host-side mirror of the reference's graph functions, issuing the batches above
+ * ------------------------------------------------------------------------------------------------ */
+
+/* HnswBuildState::new, build.rs:295-343: m in [2,100], ef_construction in [4,1000] and >= 2m
+ * (options.rs:203-225, build.rs:865-867).  The index borrows the engine (which must outlive it). */
+int hx_index_create(hx_engine *e, int m, int ef_construction, hx_index **out);
+int hx_index_destroy(hx_index *ix);
+const char *hx_index_last_error(const hx_index *ix);
+
+/* Host worker threads used by the lock-step driver (default: hardware concurrency, capped at 16). */
+int hx_index_set_threads(hx_index *ix, int n_threads);
+
+/* build_callback (build.rs:400-535) for n rows that were already appended to the engine as rows
+ * [first_row, first_row+n) (and normalised for cosine opclasses).  levels[i] is the level draw of row i
+ * (the reference draws it with an unseeded rand::random, build.rs:373-377); tids[i] its heap TID.
+ * batch == 1 reproduces the reference's strictly sequential schedule; batch > 1 runs `batch`
+ * find_element_neighbors searches in lock-step against the graph as of the batch start, then applies
+ * duplicate merge / back-links / entry-point update in row order (DESIGN.md "snapshot schedule").
+ * elem_out[i] (may be NULL) = element (row id) that holds tid i. */
+int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels,
+                    const int64_t *tids, uint32_t batch, uint32_t *elem_out);
+
+/* graph export (what create_graph_pages/write_neighbor_tuples serialise, build.rs:545-821) */
+uint32_t hx_index_size(const hx_index *ix);
+int64_t hx_index_entry(const hx_index *ix);                   /* -1 = empty */
+int hx_index_level(const hx_index *ix, uint32_t elem);        /* <0 = tombstoned duplicate */
+int hx_index_neighbors(const hx_index *ix, uint32_t elem, int layer, uint32_t *ids_out, float *dist_out); /* returns count */
+int hx_index_heaptids(const hx_index *ix, uint32_t elem, int64_t *tids_out);                              /* returns count (<= 10) */
+/* graph import: lets a rank install lists computed elsewhere (multi-GPU exchange) */
+int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t count, const uint32_t *ids, const float *dist);
+
+/* distance-evaluation counters per hot loop (SURVEY 3 "hot-loop summary"): [0] entry point,
+ * [1] search_layer expansions, [2] select_neighbors in find_element_neighbors, [3] back-link pruning, [4] scan */
+int hx_index_counters(const hx_index *ix, uint64_t counters_out[8]);
+
+/* get_scan_items + amgettuple (scan.rs:458-530, 709-876), iterative_scan = off, for nq queries in
+ * lock-step: the queries are the engine's query slots 0..nq-1 (hx_set_queries).  Per query, up to k heap
+ * TIDs nearest first with their distances; counts_out[q] = number returned. */
+int hx_index_search(hx_index *ix, uint32_t nq, uint32_t ef_search, uint32_t k,
+                    int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out);
+
+/* Iterative scan (hnsw.iterative_scan = relaxed_order | strict_order, scan.rs:794-875): per query, keeps
+ * resuming from the discarded heap until `limit` tuples for which filter_pass[tid] != 0 were produced,
+ * max_scan_tuples is exhausted, or the graph is. mode: 1 = relaxed_order, 2 = strict_order.
+ * filter_pass may be NULL (every tuple passes); it is indexed by tid, n_filter entries. */
+int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, int64_t max_scan_tuples,
+                              uint32_t limit, const uint8_t *filter_pass, uint64_t n_filter,
+                              int64_t *tids_out, float *dist_out, uint32_t *counts_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HNSWRX_H */

@@ -1,0 +1,300 @@
+"""ctypes binding of include/hnswrx.h (no arithmetic here; every call lands in libhnswrx.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+F32, F16, BIT = 0, 1, 2
+L2SQ, NEG_IP, L1, HAMMING, JACCARD = 0, 1, 2, 3, 4
+QUERY_SLOT = 0x80000000
+_NP = {F32: np.float32, F16: np.uint16, BIT: np.uint8}
+
+_lib = None
+
+
+class HxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("hnswrx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """Loads libhnswrx.so, (re)building it when hipcc is available and the sources are newer.
+    There is no fallback: if the library cannot be built or loaded this raises."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _build.stale():
+        _build.build()
+    L = C.CDLL(_build.LIB)
+    vp, i32, u32, u64, i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int64
+    sig = {
+        "hx_abi_version": (i32, []),
+        "hx_last_error": (C.c_char_p, [vp]),
+        "hx_create": (i32, [i32, i32, i32, i32, u64, C.POINTER(vp)]),
+        "hx_destroy": (i32, [vp]),
+        "hx_dim": (i32, [vp]),
+        "hx_row_bytes": (u64, [vp]),
+        "hx_num_rows": (u64, [vp]),
+        "hx_stream": (vp, [vp]),
+        "hx_append_rows": (i32, [vp, vp, u64, C.POINTER(u64)]),
+        "hx_append_rows_device": (i32, [vp, vp, u64, C.POINTER(u64)]),
+        "hx_pop_rows": (i32, [vp, u64]),
+        "hx_read_rows": (i32, [vp, u64, u64, vp]),
+        "hx_normalize_rows": (i32, [vp, u64, u64, vp]),
+        "hx_set_queries": (i32, [vp, vp, u32, i32]),
+        "hx_set_queries_device": (i32, [vp, vp, u32, i32]),
+        "hx_distances": (i32, [vp, vp, vp, u32, vp]),
+        "hx_distances_batch": (i32, [vp, u32, vp, vp, vp, vp]),
+        "hx_pairwise": (i32, [vp, vp, u32, vp]),
+        "hx_pairwise_many": (i32, [vp, u32, vp, vp, vp, vp, vp, vp]),
+        "hx_rows_equal": (i32, [vp, u32, vp, vp, vp]),
+        "hx_set_timing": (i32, [vp, i32]),
+        "hx_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
+        "hx_kernel_stats": (i32, [vp, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_double), i32]),
+        "hx_index_create": (i32, [vp, i32, i32, C.POINTER(vp)]),
+        "hx_index_destroy": (i32, [vp]),
+        "hx_index_last_error": (C.c_char_p, [vp]),
+        "hx_index_set_threads": (i32, [vp, i32]),
+        "hx_index_insert": (i32, [vp, u64, u32, vp, vp, u32, vp]),
+        "hx_index_size": (u32, [vp]),
+        "hx_index_entry": (i64, [vp]),
+        "hx_index_level": (i32, [vp, u32]),
+        "hx_index_neighbors": (i32, [vp, u32, i32, vp, vp]),
+        "hx_index_heaptids": (i32, [vp, u32, vp]),
+        "hx_index_set_neighbors": (i32, [vp, u32, i32, u32, vp, vp]),
+        "hx_index_counters": (i32, [vp, vp]),
+        "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
+        "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+ABI_SYMBOLS = None  # filled lazily by tests from include/hnswrx.h
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class Engine:
+    """hx_engine: device row store + batched distance kernels (replaces graph::DistanceFn)."""
+
+    def __init__(self, dtype, metric, dim, capacity, device=0):
+        self.dtype, self.metric, self.dim = dtype, metric, dim
+        h = C.c_void_p()
+        rc = lib().hx_create(device, dtype, metric, dim, int(capacity), C.byref(h))
+        if rc:
+            raise HxError(rc, lib().hx_last_error(None).decode())
+        self.h = h
+        self.row_bytes = lib().hx_row_bytes(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().hx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc:
+            raise HxError(rc, lib().hx_last_error(self.h).decode())
+
+    def _rows(self, a):
+        a = np.ascontiguousarray(a, dtype=_NP[self.dtype])
+        if a.nbytes % self.row_bytes:
+            raise ValueError("row payload size mismatch")
+        return a, a.nbytes // self.row_bytes
+
+    @property
+    def num_rows(self):
+        return lib().hx_num_rows(self.h)
+
+    def append(self, rows):
+        a, n = self._rows(rows)
+        first = C.c_uint64()
+        self._ck(lib().hx_append_rows(self.h, _p(a), n, C.byref(first)))
+        return first.value
+
+    def append_device(self, dev_ptr, n):
+        first = C.c_uint64()
+        self._ck(lib().hx_append_rows_device(self.h, C.c_void_p(dev_ptr), n, C.byref(first)))
+        return first.value
+
+    def pop(self, n):
+        self._ck(lib().hx_pop_rows(self.h, n))
+
+    def read_rows(self, first, n):
+        out = np.empty((n, self.row_bytes // np.dtype(_NP[self.dtype]).itemsize), _NP[self.dtype])
+        self._ck(lib().hx_read_rows(self.h, first, n, _p(out)))
+        return out
+
+    def normalize_rows(self, first, n):
+        norms = np.empty(n, np.float64)
+        self._ck(lib().hx_normalize_rows(self.h, first, n, _p(norms)))
+        return norms
+
+    def set_queries(self, q, normalize=False):
+        a, n = self._rows(q)
+        self._ck(lib().hx_set_queries(self.h, _p(a), n, int(normalize)))
+        return n
+
+    def set_queries_device(self, dev_ptr, n, normalize=False):
+        self._ck(lib().hx_set_queries_device(self.h, C.c_void_p(dev_ptr), n, int(normalize)))
+
+    def distances(self, query, row_ids):
+        q, _ = self._rows(query)
+        ids = _u32(row_ids)
+        out = np.empty(len(ids), np.float32)
+        self._ck(lib().hx_distances(self.h, _p(q), _p(ids), len(ids), _p(out)))
+        return out
+
+    def distances_batch(self, group_query, group_offsets, row_ids):
+        gq, go, ids = _u32(group_query), _u32(group_offsets), _u32(row_ids)
+        out = np.empty(len(ids), np.float32)
+        self._ck(lib().hx_distances_batch(self.h, len(gq), _p(gq), _p(go), _p(ids), _p(out)))
+        return out
+
+    def pairwise(self, ids):
+        ids = _u32(ids)
+        out = np.empty((len(ids), len(ids)), np.float32)
+        self._ck(lib().hx_pairwise(self.h, _p(ids), len(ids), _p(out)))
+        return out
+
+    def pairwise_many(self, groups):
+        """groups: list of (A_ids, B_ids or None).  Returns one array per group: packed lower triangle
+        (B None) or an (na, nb) rectangle."""
+        off, na, nb, ids, ooff, n_out = [0], [], [], [], [], 0
+        for a, b in groups:
+            b = [] if b is None else b
+            ids.extend(a)
+            ids.extend(b)
+            na.append(len(a))
+            nb.append(len(b))
+            off.append(len(ids))
+            ooff.append(n_out)
+            n_out += len(a) * len(b) if len(b) else len(a) * (len(a) - 1) // 2
+        off, ids = _u32(off), _u32(ids)
+        na, nb = np.asarray(na, np.uint16), np.asarray(nb, np.uint16)
+        ooff_a = np.asarray(ooff, np.uint64)
+        out = np.empty(max(n_out, 1), np.float32)
+        self._ck(lib().hx_pairwise_many(self.h, len(groups), _p(off), _p(na), _p(nb), _p(ids), _p(ooff_a), _p(out)))
+        res = []
+        for g, (a, b) in enumerate(groups):
+            if b is None or len(b) == 0:
+                res.append(out[ooff[g]:ooff[g] + len(a) * (len(a) - 1) // 2].copy())
+            else:
+                res.append(out[ooff[g]:ooff[g] + len(a) * len(b)].reshape(len(a), len(b)).copy())
+        return res
+
+    def rows_equal(self, a_ids, b_ids):
+        a, b = _u32(a_ids), _u32(b_ids)
+        out = np.empty(len(a), np.uint8)
+        self._ck(lib().hx_rows_equal(self.h, len(a), _p(a), _p(b), _p(out)))
+        return out.astype(bool)
+
+    def set_timing(self, on=True):
+        self._ck(lib().hx_set_timing(self.h, int(on)))
+
+    def kernel_stats(self, kind, reset=False):
+        l, u, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        self._ck(lib().hx_kernel_stats(self.h, kind, C.byref(l), C.byref(u), C.byref(ms), int(reset)))
+        return {"launches": l.value, "units": u.value, "ms": ms.value}
+
+
+class Index:
+    """hx_index: host-side HNSW graph (graph/mod.rs + build.rs + scan.rs control flow) over an Engine."""
+
+    def __init__(self, engine, m=16, ef_construction=64):
+        self.engine, self.m, self.efc = engine, m, ef_construction
+        h = C.c_void_p()
+        rc = lib().hx_index_create(engine.h, m, ef_construction, C.byref(h))
+        if rc:
+            raise HxError(rc, lib().hx_last_error(engine.h).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().hx_index_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _ck(self, rc):
+        if rc:
+            raise HxError(rc, lib().hx_index_last_error(self.h).decode())
+
+    def set_threads(self, n):
+        self._ck(lib().hx_index_set_threads(self.h, n))
+
+    def insert(self, first_row, levels, tids=None, batch=1):
+        levels = np.ascontiguousarray(levels, np.int32)
+        n = len(levels)
+        tids = np.arange(first_row, first_row + n, dtype=np.int64) if tids is None else np.ascontiguousarray(tids, np.int64)
+        out = np.empty(n, np.uint32)
+        self._ck(lib().hx_index_insert(self.h, first_row, n, _p(levels), _p(tids), batch, _p(out)))
+        return out
+
+    @property
+    def size(self):
+        return lib().hx_index_size(self.h)
+
+    @property
+    def entry(self):
+        return lib().hx_index_entry(self.h)
+
+    def level(self, e):
+        return lib().hx_index_level(self.h, e)
+
+    def neighbors(self, e, layer):
+        ids = np.empty(2 * self.m, np.uint32)
+        d = np.empty(2 * self.m, np.float32)
+        n = lib().hx_index_neighbors(self.h, e, layer, _p(ids), _p(d))
+        if n < 0:
+            return None, None
+        return ids[:n].copy(), d[:n].copy()
+
+    def heaptids(self, e):
+        t = np.empty(10, np.int64)
+        n = lib().hx_index_heaptids(self.h, e, _p(t))
+        return t[:n].tolist()
+
+    def set_neighbors(self, e, layer, ids, dist):
+        ids, dist = _u32(ids), np.ascontiguousarray(dist, np.float32)
+        self._ck(lib().hx_index_set_neighbors(self.h, e, layer, len(ids), _p(ids), _p(dist)))
+
+    def counters(self):
+        c = np.zeros(8, np.uint64)
+        self._ck(lib().hx_index_counters(self.h, _p(c)))
+        return c
+
+    def search(self, nq, ef_search, k):
+        tids = np.full((nq, k), -1, np.int64)
+        d = np.full((nq, k), np.inf, np.float32)
+        el = np.zeros((nq, k), np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        self._ck(lib().hx_index_search(self.h, nq, ef_search, k, _p(tids), _p(d), _p(el), _p(cnt)))
+        return tids, d, el, cnt
+
+    def search_iterative(self, nq, ef_search, mode, max_scan_tuples, limit, filter_pass=None):
+        tids = np.full((nq, limit), -1, np.int64)
+        d = np.full((nq, limit), np.inf, np.float32)
+        cnt = np.zeros(nq, np.uint32)
+        f = None if filter_pass is None else np.ascontiguousarray(filter_pass, np.uint8)
+        self._ck(lib().hx_index_search_iterative(self.h, nq, ef_search, mode, max_scan_tuples, limit, _p(f),
+                                                 0 if f is None else len(f), _p(tids), _p(d), _p(cnt)))
+        return tids, d, cnt

@@ -1,0 +1,818 @@
+// hx_index.cpp -- host-side HNSW graph driver: the reference's graph functions re-designed as resumable
+// state machines that run MANY inserts / queries in lock-step and hand each step's candidate rows to the
+// device kernels of hx_engine.hip in one launch.
+//
+// Mirrors (same names, same control flow per insert/query; every distance comes from the engine):
+//   search_layer               src/graph/mod.rs:161-255      -> SearchCore (build mode)
+//   select_neighbors           src/graph/mod.rs:269-308      -> SelectTask
+//   check_element_closer       src/graph/mod.rs:315-339      -> SelectTask::process_block
+//   find_element_neighbors     src/graph/mod.rs:355-427      -> InsertTask
+//   update_neighbor_connections src/graph/mod.rs:442-489     -> BacklinkTask
+//   build_callback             src/index/build.rs:400-535    -> hx_index_insert
+//   search_layer_disk          src/index/scan.rs:302-448     -> SearchCore (scan mode)
+//   get_scan_items / resume_scan_items / amgettuple  src/index/scan.rs:458-577, 709-876 -> QueryTask
+//
+// Why lock-step: one expansion evaluates <= 2M rows (32 rows x 3 KB at d=768), far too little to keep an
+// MI355X busy.  The distances of one expansion do not depend on heap state, so the host computes them
+// for thousands of independent searches at once and then replays each search's heap logic in the
+// reference's order: per search the control flow is identical to the sequential code.
+//
+// The heaps restate Rust std::collections::BinaryHeap (sift_up / sift_down_to_bottom) so that the order
+// among equal distances matches; see DESIGN.md "tie order".
+#include "hx_internal.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct Cand { float d; uint32_t id; };
+
+// ------------------------------------------------------------------------------------------------
+// BinaryHeap with Rust std's exact sift order.  NEAREST=true: smallest distance on top
+// (NearestCandidate, graph/mod.rs:103-112); false: largest on top (FurthestCandidate, :131-139).
+// ------------------------------------------------------------------------------------------------
+template <bool NEAREST> struct RHeap {
+    std::vector<Cand> v;
+    static bool le(const Cand &a, const Cand &b) { return NEAREST ? !(b.d > a.d) : !(a.d > b.d); }   // cmp(a,b) != Greater
+    bool empty() const { return v.empty(); }
+    size_t size() const { return v.size(); }
+    const Cand &top() const { return v[0]; }
+    void clear() { v.clear(); }
+    size_t sift_up(size_t start, size_t pos)
+    {
+        Cand e = v[pos];
+        while (pos > start) {
+            size_t parent = (pos - 1) / 2;
+            if (le(e, v[parent])) break;
+            v[pos] = v[parent]; pos = parent;
+        }
+        v[pos] = e;
+        return pos;
+    }
+    void push(Cand c) { v.push_back(c); sift_up(0, v.size() - 1); }
+    void sift_down_to_bottom(size_t pos)
+    {
+        const size_t end = v.size(), start = pos;
+        Cand e = v[pos];
+        size_t child = 2 * pos + 1;
+        while (end >= 2 && child <= end - 2) {
+            if (le(v[child], v[child + 1])) child += 1;
+            v[pos] = v[child]; pos = child; child = 2 * pos + 1;
+        }
+        if (child == end - 1) { v[pos] = v[child]; pos = child; }
+        v[pos] = e;
+        sift_up(start, pos);
+    }
+    bool pop(Cand &out)
+    {
+        if (v.empty()) return false;
+        Cand item = v.back(); v.pop_back();
+        if (!v.empty()) { std::swap(item, v[0]); sift_down_to_bottom(0); }
+        out = item;
+        return true;
+    }
+};
+
+// visited set: open addressing on row ids (only membership matters: HashSet<usize>, graph/mod.rs:171)
+struct VisitedSet {
+    std::vector<uint32_t> tab; size_t n = 0, mask = 0;
+    static constexpr uint32_t EMPTY = 0xffffffffu;
+    void reset(size_t expect)
+    {
+        size_t cap = 256; while (cap < expect * 2) cap <<= 1;
+        if (tab.size() != cap) tab.assign(cap, EMPTY); else std::fill(tab.begin(), tab.end(), EMPTY);
+        mask = cap - 1; n = 0;
+    }
+    static inline uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+    void grow()
+    {
+        std::vector<uint32_t> old; old.swap(tab);
+        tab.assign(old.size() * 2, EMPTY); mask = tab.size() - 1; n = 0;
+        for (uint32_t k : old) if (k != EMPTY) test_and_set(k);
+    }
+    // returns true if already present
+    bool test_and_set(uint32_t k)
+    {
+        if ((n + 1) * 2 > tab.size()) grow();
+        size_t i = mix(k) & mask;
+        while (true) {
+            uint32_t t = tab[i];
+            if (t == k) return true;
+            if (t == EMPTY) { tab[i] = k; n++; return false; }
+            i = (i + 1) & mask;
+        }
+    }
+    bool contains(uint32_t k) const
+    {
+        if (tab.empty()) return false;
+        size_t i = mix(k) & mask;
+        while (true) { uint32_t t = tab[i]; if (t == k) return true; if (t == EMPTY) return false; i = (i + 1) & mask; }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// graph storage (GraphElement / NeighborArray, graph/mod.rs:24-84), flat arrays indexed by row id
+// ------------------------------------------------------------------------------------------------
+constexpr int HEAPTIDS = 10;   // hnsw_constants.rs:85
+
+struct Graph {
+    int m = 16;
+    std::vector<int32_t> level;              // < 0: tombstoned duplicate
+    std::vector<uint16_t> n0_cnt; std::vector<Cand> n0;             // layer 0: stride 2m
+    std::vector<uint64_t> up_off;                                    // first slot of layers 1..level in `up`
+    std::vector<Cand> up; std::vector<uint16_t> up_cnt;              // up: stride m per layer; up_cnt per (elem, layer)
+    std::vector<uint64_t> upc_off;
+    std::vector<std::array<int64_t, HEAPTIDS>> tids; std::vector<uint8_t> ntids;
+    int64_t entry = -1;
+
+    uint32_t size() const { return (uint32_t)level.size(); }
+    int lm(int layer) const { return layer == 0 ? 2 * m : m; }       // hnsw_get_layer_m, hnsw_constants.rs:122-128
+    uint32_t add(int lv)
+    {
+        uint32_t id = size();
+        level.push_back(lv);
+        n0_cnt.push_back(0); n0.resize(n0.size() + 2 * (size_t)m);
+        up_off.push_back(up.size()); upc_off.push_back(up_cnt.size());
+        if (lv > 0) { up.resize(up.size() + (size_t)lv * m); up_cnt.resize(up_cnt.size() + lv, 0); }
+        tids.emplace_back(); ntids.push_back(0);
+        return id;
+    }
+    Cand *list(uint32_t e, int layer) { return layer == 0 ? &n0[(size_t)e * 2 * m] : &up[up_off[e] + (size_t)(layer - 1) * m]; }
+    const Cand *list(uint32_t e, int layer) const { return const_cast<Graph *>(this)->list(e, layer); }
+    uint16_t &cnt(uint32_t e, int layer) { return layer == 0 ? n0_cnt[e] : up_cnt[upc_off[e] + (layer - 1)]; }
+    uint16_t cnt(uint32_t e, int layer) const { return const_cast<Graph *>(this)->cnt(e, layer); }
+};
+
+static void stable_sort_asc(std::vector<Cand> &v) { std::stable_sort(v.begin(), v.end(), [](const Cand &a, const Cand &b) { return a.d < b.d; }); }
+static void stable_sort_desc(std::vector<Cand> &v) { std::stable_sort(v.begin(), v.end(), [](const Cand &a, const Cand &b) { return b.d < a.d; }); }
+
+// ------------------------------------------------------------------------------------------------
+// lock-step task protocol
+// ------------------------------------------------------------------------------------------------
+struct PairGroup { uint16_t na, nb; };
+
+struct LsTask {
+    // request produced by advance(): at most one distance group and any number of pair groups
+    uint32_t q_sel = 0;
+    std::vector<uint32_t> dist_ids;
+    std::vector<PairGroup> pgroups; std::vector<uint32_t> pair_ids;
+    // where the scheduler put the results of the last request
+    size_t dist_off = 0, pair_out_off = 0;
+    uint64_t n_dist = 0, n_pair = 0;          // distance evaluations requested by this task
+    virtual ~LsTask() {}
+    // consumes the results of its previous request (dres/pres point at this task's slices) and either
+    // posts a new request (returns true) or finishes (returns false)
+    virtual bool advance(const float *dres, const float *pres) = 0;
+    void clear_req() { dist_ids.clear(); pgroups.clear(); pair_ids.clear(); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Algorithm 2, resumable.  Build mode = search_layer (graph/mod.rs:161-255); scan mode =
+// search_layer_disk (scan.rs:302-448) with its `discarded` heap for iterative scans.
+// ------------------------------------------------------------------------------------------------
+struct SearchCore {
+    const Graph *g = nullptr;
+    int layer = 0; size_t ef = 1; bool scan_mode = false;
+    RHeap<true> C; RHeap<false> W; size_t wlen = 0;
+    VisitedSet own_vis; VisitedSet *vis = nullptr;
+    RHeap<true> *discarded = nullptr;
+    std::vector<uint32_t> pend;
+    bool finished = true;
+
+    void start(const Graph *gr, const std::vector<Cand> &ep, size_t ef_, int layer_, bool scan, VisitedSet *shared_vis,
+               RHeap<true> *disc, bool add_entry_to_visited)
+    {
+        g = gr; ef = ef_; layer = layer_; scan_mode = scan; discarded = disc;
+        C.clear(); W.clear(); wlen = 0; pend.clear(); finished = false;
+        if (shared_vis) vis = shared_vis; else { own_vis.reset(ef * 2 + 64); vis = &own_vis; }
+        for (const Cand &e : ep) {
+            if (add_entry_to_visited) vis->test_and_set(e.id);
+            C.push(e); W.push(e); wlen++;
+        }
+    }
+    inline void apply(uint32_t e, float d)
+    {
+        const bool always_add = wlen < ef;
+        bool add;
+        if (!scan_mode) { const float f = W.empty() ? FLT_MAX : W.top().d; add = d < f || always_add; }          // mod.rs:226-229
+        else { const double f = W.empty() ? DBL_MAX : (double)W.top().d; add = !(!always_add && (double)d >= f); } // scan.rs:372-383,195-200
+        if (add) {
+            Cand c{d, e};
+            C.push(c); W.push(c); wlen++;
+            if (wlen > ef) { Cand ev; W.pop(ev); wlen--; if (discarded) discarded->push(ev); }   // mod.rs:239-242 / scan.rs:420-429
+        } else if (discarded) {
+            discarded->push(Cand{d, e});                                                        // scan.rs:385-404
+        }
+    }
+    // returns true when `pend` holds rows whose distances are needed
+    bool run(const float *res)
+    {
+        if (!pend.empty()) { for (size_t k = 0; k < pend.size(); k++) apply(pend[k], res[k]); pend.clear(); }
+        Cand c;
+        while (C.pop(c)) {
+            if (!scan_mode) { const float f = W.empty() ? FLT_MAX : W.top().d; if (c.d > f) break; }
+            else { const double f = W.empty() ? DBL_MAX : (double)W.top().d; if ((double)c.d > f) { if (discarded) discarded->push(c); break; } }
+            if (g->level[c.id] < layer) continue;                                    // mod.rs:198-200
+            const Cand *nb = g->list(c.id, layer); const uint16_t n = g->cnt(c.id, layer);
+            for (uint16_t k = 0; k < n; k++) {
+                const uint32_t e = nb[k].id;
+                if (vis->test_and_set(e)) continue;                                  // mod.rs:206-209
+                if (g->level[e] < layer) continue;                                   // mod.rs:213-216 (never enters C/W/discarded in scan.rs either)
+                pend.push_back(e);
+            }
+            if (!pend.empty()) return true;
+        }
+        if (discarded) { Cand r; while (C.pop(r)) discarded->push(r); }              // scan.rs:433-438
+        finished = true;
+        return false;
+    }
+    void results_asc(std::vector<Cand> &out) const { out = W.v; stable_sort_asc(out); }    // mod.rs:248-254
+    void results_desc(std::vector<Cand> &out) const { out = W.v; stable_sort_desc(out); }  // scan.rs:441-446 (nearest last)
+};
+
+// ------------------------------------------------------------------------------------------------
+// select_neighbors (graph/mod.rs:269-308), resumable: candidates are processed in blocks; the
+// operands of check_element_closer for a whole block are fetched as pair groups in one step.
+// ------------------------------------------------------------------------------------------------
+struct SelectTask {
+    const std::vector<Cand> *cands = nullptr; size_t maxn = 0;
+    std::vector<Cand> R, disc; std::vector<int> r_blk;     // r_blk[i] = index inside the current block of R[i], or -1
+    size_t pos = 0, blk = 0, r0 = 0;
+    bool finished = true;
+    static constexpr size_t FIRST_BLOCK = 48, NEXT_BLOCK = 32, RCHUNK = 32;
+
+    void start(const std::vector<Cand> *c, size_t maxn_)
+    {
+        cands = c; maxn = maxn_; R.clear(); disc.clear(); r_blk.clear(); pos = 0; blk = 0; r0 = 0; finished = false;
+        if (c->size() <= maxn) { R = *c; finished = true; }                          // mod.rs:276-278
+    }
+    // posts the pair groups of the next block into t; returns false when there is nothing left to ask
+    bool post(LsTask &t)
+    {
+        const size_t n = cands->size();
+        if (finished) return false;
+        if (R.size() >= maxn || pos >= n) { finish(); return false; }
+        r0 = R.size();
+        blk = std::min(n - pos, r0 == 0 ? FIRST_BLOCK : NEXT_BLOCK);
+        for (auto &x : r_blk) x = -1;
+        if (blk >= 2) {                                                              // triangle inside the block
+            t.pgroups.push_back(PairGroup{(uint16_t)blk, 0});
+            for (size_t k = 0; k < blk; k++) t.pair_ids.push_back((*cands)[pos + k].id);
+            t.n_pair += blk * (blk - 1) / 2;
+        }
+        for (size_t c0 = 0; c0 < r0; c0 += RCHUNK) {                                 // block x (R as of block start)
+            const size_t nbk = std::min(RCHUNK, r0 - c0);
+            t.pgroups.push_back(PairGroup{(uint16_t)blk, (uint16_t)nbk});
+            for (size_t k = 0; k < blk; k++) t.pair_ids.push_back((*cands)[pos + k].id);
+            for (size_t j = 0; j < nbk; j++) t.pair_ids.push_back(R[c0 + j].id);
+            t.n_pair += blk * nbk;
+        }
+        if (t.pgroups.empty()) {   // single candidate and empty R: nothing to compare against
+            process_block(nullptr);
+            return post(t);
+        }
+        return true;
+    }
+    void process_block(const float *res)
+    {
+        const float *tri = nullptr; const float *rect = res;
+        if (blk >= 2) { tri = res; rect = res + blk * (blk - 1) / 2; }
+        for (size_t k = 0; k < blk; k++) {
+            if (R.size() >= maxn) break;                                             // mod.rs:285-287
+            const Cand e = (*cands)[pos + k];
+            bool closer = true;                                                      // check_element_closer, mod.rs:315-339
+            for (size_t ri = 0; ri < R.size(); ri++) {
+                float d;
+                if (ri < r0) { const size_t chunk = ri / RCHUNK, j = ri % RCHUNK, nbk = std::min(RCHUNK, r0 - chunk * RCHUNK);
+                               d = rect[chunk * RCHUNK * blk + k * nbk + j]; }
+                else { const size_t kk = (size_t)r_blk[ri]; d = tri[k * (k - 1) / 2 + kk]; }
+                if (d <= e.d) { closer = false; break; }                             // mod.rs:333-335
+            }
+            if (closer) { R.push_back(e); r_blk.push_back((int)k); } else disc.push_back(e);
+        }
+        pos += blk;
+    }
+    void finish()
+    {
+        for (const Cand &d : disc) { if (R.size() >= maxn) break; R.push_back(d); }  // mod.rs:300-305
+        finished = true;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// find_element_neighbors (graph/mod.rs:355-427) for one new element
+// ------------------------------------------------------------------------------------------------
+struct InsertTask : LsTask {
+    const Graph *g; uint32_t id; int new_level, entry_level; uint32_t entry; int efc;
+    enum { S_INIT, S_ENTRY, S_GREEDY, S_SEARCH, S_SELECT, S_DONE } st = S_INIT;
+    int lc = 0;
+    std::vector<Cand> ep, w;
+    SearchCore sc; SelectTask sel;
+    std::vector<std::vector<Cand>> nb;     // selected neighbours per layer 0..new_level
+
+    bool post_search() { dist_ids = sc.pend; q_sel = id; n_dist += dist_ids.size(); return true; }
+    bool advance(const float *dres, const float *pres) override
+    {
+        clear_req();
+        for (;;) {
+            switch (st) {
+            case S_INIT:
+                nb.assign(new_level + 1, {});
+                dist_ids.push_back(entry); q_sel = id; n_dist += 1; st = S_ENTRY;    // mod.rs:371-377
+                return true;
+            case S_ENTRY:
+                ep.assign(1, Cand{dres[0], entry});
+                lc = entry_level; st = S_GREEDY;
+                if (lc >= new_level + 1) sc.start(g, ep, 1, lc, false, nullptr, nullptr, true);
+                dres = nullptr;
+                break;
+            case S_GREEDY:                                                           // mod.rs:385-399
+                if (lc < new_level + 1) {
+                    lc = std::min(new_level, entry_level); st = S_SEARCH;
+                    if (lc >= 0) sc.start(g, ep, (size_t)efc, lc, false, nullptr, nullptr, true);
+                    break;
+                }
+                if (sc.run(dres)) return post_search();
+                dres = nullptr;
+                sc.results_asc(w);
+                if (!w.empty()) ep.assign(1, w[0]);
+                lc--;
+                if (lc >= new_level + 1) sc.start(g, ep, 1, lc, false, nullptr, nullptr, true);
+                break;
+            case S_SEARCH:                                                           // mod.rs:403-416
+                if (lc < 0) { st = S_DONE; break; }
+                if (sc.run(dres)) return post_search();
+                dres = nullptr;
+                sc.results_asc(w);
+                sel.start(&w, (size_t)g->lm(lc));
+                st = S_SELECT; pres = nullptr;
+                break;
+            case S_SELECT:                                                           // mod.rs:419-425
+                if (pres) { sel.process_block(pres); pres = nullptr; }
+                if (sel.post(*this)) return true;
+                nb[lc] = sel.R;
+                ep = w;
+                lc--;
+                st = S_SEARCH;
+                if (lc >= 0) sc.start(g, ep, (size_t)efc, lc, false, nullptr, nullptr, true);
+                break;
+            case S_DONE:
+                return false;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// update_neighbor_connections (graph/mod.rs:442-489), regrouped: one task per (neighbour, layer) list,
+// applying that list's back-links in insertion order.  Lists are independent of each other.
+// ------------------------------------------------------------------------------------------------
+struct BackOp { uint32_t target; int layer; uint32_t new_id; float d; };
+
+struct BacklinkTask : LsTask {
+    Graph *g; uint32_t target; int layer; std::vector<BackOp> ops; size_t k = 0;
+    std::vector<Cand> all; SelectTask sel; bool selecting = false;
+    bool advance(const float *, const float *pres) override
+    {
+        clear_req();
+        const size_t lm = (size_t)g->lm(layer);
+        for (;;) {
+            if (selecting) {
+                if (pres) { sel.process_block(pres); pres = nullptr; }
+                if (sel.post(*this)) return true;
+                Cand *lst = g->list(target, layer);
+                for (size_t i = 0; i < sel.R.size(); i++) lst[i] = sel.R[i];         // mod.rs:484-485
+                g->cnt(target, layer) = (uint16_t)sel.R.size();
+                selecting = false; k++;
+            }
+            if (k >= ops.size()) return false;
+            const BackOp &op = ops[k];
+            Cand *lst = g->list(target, layer); uint16_t &c = g->cnt(target, layer);
+            if (c < lm) { lst[c++] = Cand{op.d, op.new_id}; k++; continue; }         // mod.rs:469-471
+            all.assign(lst, lst + c); all.push_back(Cand{op.d, op.new_id});          // mod.rs:474-482
+            stable_sort_asc(all);
+            sel.start(&all, lm);
+            selecting = true;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// get_scan_items + amgettuple (scan.rs:458-530, 709-876) for one query slot
+// ------------------------------------------------------------------------------------------------
+struct QueryTask : LsTask {
+    const Graph *g; uint32_t slot; size_t ef_search; int mode; int64_t max_scan_tuples; uint32_t limit;
+    const uint8_t *filter = nullptr; uint64_t n_filter = 0;
+    enum { Q_INIT, Q_ENTRY, Q_GREEDY, Q_GROUND, Q_EMIT, Q_RESUME, Q_DONE } st = Q_INIT;
+    int lc = 0;
+    std::vector<Cand> ep, results;        // results: nearest LAST
+    SearchCore sc; VisitedSet visited; RHeap<true> discarded;
+    int64_t tuples = 0; double previous_distance = -HUGE_VAL;
+    // output
+    std::vector<int64_t> out_tid; std::vector<float> out_d; std::vector<uint32_t> out_elem;
+
+    bool post_search() { dist_ids = sc.pend; q_sel = HX_QUERY_SLOT | slot; n_dist += dist_ids.size(); return true; }
+    bool pass(int64_t tid) const { return !filter || (tid >= 0 && (uint64_t)tid < n_filter && filter[tid]); }
+    bool advance(const float *dres, const float *) override
+    {
+        clear_req();
+        const bool iterative = mode != 0;
+        for (;;) {
+            switch (st) {
+            case Q_INIT:
+                if (g->entry < 0) { st = Q_DONE; break; }                            // scan.rs:469-472
+                dist_ids.push_back((uint32_t)g->entry); q_sel = HX_QUERY_SLOT | slot; n_dist += 1; st = Q_ENTRY;
+                return true;
+            case Q_ENTRY:
+                ep.assign(1, Cand{dres[0], (uint32_t)g->entry}); dres = nullptr;
+                lc = g->level[g->entry]; st = Q_GREEDY;
+                if (lc >= 1) sc.start(g, ep, 1, lc, true, nullptr, nullptr, true);
+                break;
+            case Q_GREEDY:                                                           // scan.rs:491-512
+                if (lc < 1) {
+                    if (iterative) visited.reset(ef_search * (size_t)g->m * 2);
+                    sc.start(g, ep, ef_search, 0, true, iterative ? &visited : nullptr, iterative ? &discarded : nullptr, true);
+                    st = Q_GROUND; break;
+                }
+                if (sc.run(dres)) return post_search();
+                dres = nullptr;
+                sc.results_desc(results);
+                if (results.empty()) { st = Q_DONE; break; }
+                ep.assign(1, results.back());
+                lc--;
+                if (lc >= 1) sc.start(g, ep, 1, lc, true, nullptr, nullptr, true);
+                break;
+            case Q_GROUND:                                                           // scan.rs:515-528
+            case Q_RESUME:
+                if (sc.run(dres)) return post_search();
+                dres = nullptr;
+                sc.results_desc(results);
+                st = Q_EMIT;
+                break;
+            case Q_EMIT:                                                             // scan.rs:794-875
+                while (!results.empty() && out_tid.size() < limit) {
+                    const Cand scd = results.back(); results.pop_back();
+                    const uint8_t nt = g->ntids[scd.id];
+                    if (nt == 0) continue;                                           // scan.rs:866-868
+                    tuples++;
+                    for (int t = (int)nt - 1; t >= 0 && out_tid.size() < limit; t--) {   // heaptids.pop()
+                        if (mode == 2) { if ((double)scd.d < previous_distance) continue; previous_distance = (double)scd.d; }
+                        const int64_t tid = g->tids[scd.id][t];
+                        if (!pass(tid)) continue;
+                        out_tid.push_back(tid); out_d.push_back(scd.d); out_elem.push_back(scd.id);
+                    }
+                }
+                if (out_tid.size() >= limit || !iterative) { st = Q_DONE; break; }
+                // results exhausted, iterative scan: scan.rs:817-858
+                if (tuples >= max_scan_tuples) {
+                    Cand one;
+                    if (!discarded.pop(one)) { st = Q_DONE; break; }
+                    results.assign(1, one);
+                    break;
+                }
+                if (discarded.empty()) { st = Q_DONE; break; }                       // resume_scan_items, scan.rs:548-550
+                ep.clear();
+                { Cand x; while (ep.size() < ef_search && discarded.pop(x)) ep.push_back(x); }
+                sc.start(g, ep, ef_search, 0, true, &visited, &discarded, false);
+                st = Q_RESUME;
+                break;
+            case Q_DONE:
+                return false;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// tiny persistent thread pool: parallel_for over task indices
+// ------------------------------------------------------------------------------------------------
+struct Pool {
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, cv_done;
+    std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}; size_t chunk = 1;
+    uint64_t gen = 0; int busy = 0; bool stop = false;
+    explicit Pool(int nt) { for (int i = 0; i < nt; i++) th.emplace_back([this] { loop(); }); }
+    ~Pool() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
+    void work() { for (;;) { size_t b = next.fetch_add(chunk); if (b >= n) break; size_t e = std::min(n, b + chunk); for (size_t i = b; i < e; i++) fn(i); } }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+            work();
+            { std::lock_guard<std::mutex> l(mu); if (--busy == 0) cv_done.notify_one(); }
+        }
+    }
+    void parallel_for(size_t count, const std::function<void(size_t)> &f)
+    {
+        if (count == 0) return;
+        if (th.empty() || count < 64) { for (size_t i = 0; i < count; i++) f(i); return; }
+        { std::lock_guard<std::mutex> l(mu); fn = f; n = count; next = 0; chunk = std::max<size_t>(1, count / (th.size() * 8 + 8)); busy = (int)th.size(); gen++; }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> l(mu); cv_done.wait(l, [&] { return busy == 0; });
+    }
+};
+
+} // namespace
+
+// ================================================================================================
+struct hx_index {
+    hx_engine *e = nullptr;
+    Graph g; int efc = 64;
+    std::unique_ptr<Pool> pool; int n_threads = 0;
+    uint64_t counters[8] = {0};
+    std::string err;
+    int fail(int code, const std::string &m) { err = m; return code; }
+
+    // Runs tasks to completion in lock-step: every round, every live task's request goes into ONE
+    // distance launch and ONE pair launch.
+    int run_lockstep(std::vector<LsTask *> &tasks)
+    {
+        std::vector<LsTask *> live = tasks;
+        std::vector<uint8_t> alive(live.size(), 1);
+        bool first = true;
+        std::vector<size_t> pair_ids_off;
+        while (!live.empty()) {
+            const float *dbase = e->ch.h_out, *pbase = e->ch.h_pout;
+            pool->parallel_for(live.size(), [&](size_t i) {
+                LsTask *t = live[i];
+                alive[i] = t->advance(first ? nullptr : dbase + t->dist_off, first ? nullptr : pbase + t->pair_out_off) ? 1 : 0;
+            });
+            first = false;
+            // compact + assign offsets
+            size_t w = 0, n_dgroups = 0, n_dids = 0, n_pgroups = 0, n_pids = 0, n_pout = 0;
+            pair_ids_off.clear();
+            for (size_t i = 0; i < live.size(); i++) {
+                if (!alive[i]) continue;
+                LsTask *t = live[i];
+                t->dist_off = n_dids;
+                if (!t->dist_ids.empty()) { n_dgroups++; n_dids += t->dist_ids.size(); }
+                t->pair_out_off = n_pout;
+                pair_ids_off.push_back(n_pids);
+                size_t idp = 0;
+                for (const PairGroup &pg : t->pgroups) {
+                    n_pgroups++; idp += (size_t)pg.na + pg.nb;
+                    n_pout += pg.nb ? (size_t)pg.na * pg.nb : (size_t)pg.na * (pg.na - 1) / 2;
+                }
+                n_pids += idp;
+                live[w++] = t;
+            }
+            live.resize(w); alive.assign(w, 1);
+            if (live.empty()) break;
+            int rc;
+            if ((rc = e->ensure_dist_capacity(n_dgroups, n_dids))) return fail(rc, e->err);
+            if ((rc = e->ensure_pair_capacity(n_pgroups, n_pids, n_pout))) return fail(rc, e->err);
+            // fill the pinned request arrays (serial prefix for group slots, parallel copy of ids)
+            std::vector<uint32_t> dg_slot(live.size()), pg_slot(live.size());
+            { size_t dg = 0, pg = 0; for (size_t i = 0; i < live.size(); i++) { dg_slot[i] = (uint32_t)dg; pg_slot[i] = (uint32_t)pg; if (!live[i]->dist_ids.empty()) dg++; pg += live[i]->pgroups.size(); } }
+            HxChannel &c = e->ch;
+            pool->parallel_for(live.size(), [&](size_t i) {
+                LsTask *t = live[i];
+                if (!t->dist_ids.empty()) {
+                    const uint32_t s = dg_slot[i];
+                    c.h_grp_q[s] = t->q_sel; c.h_grp_off[s] = (uint32_t)t->dist_off;
+                    memcpy(c.h_ids + t->dist_off, t->dist_ids.data(), t->dist_ids.size() * sizeof(uint32_t));
+                }
+                if (!t->pgroups.empty()) {
+                    size_t ido = pair_ids_off[i], oo = t->pair_out_off; uint32_t s = pg_slot[i];
+                    memcpy(c.h_pids + ido, t->pair_ids.data(), t->pair_ids.size() * sizeof(uint32_t));
+                    for (const PairGroup &pg : t->pgroups) {
+                        c.h_pg_off[s] = (uint32_t)ido; c.h_pg_na[s] = pg.na; c.h_pg_nb[s] = pg.nb; c.h_pg_out_off[s] = oo;
+                        ido += (size_t)pg.na + pg.nb;
+                        oo += pg.nb ? (size_t)pg.na * pg.nb : (size_t)pg.na * (pg.na - 1) / 2;
+                        s++;
+                    }
+                }
+            });
+            c.h_grp_off[n_dgroups] = (uint32_t)n_dids;
+            c.h_pg_off[n_pgroups] = (uint32_t)n_pids;
+            if ((rc = e->run_dist((uint32_t)n_dgroups, (uint32_t)n_dids))) return fail(rc, e->err);
+            if ((rc = e->run_pair((uint32_t)n_pgroups, (uint32_t)n_pids, n_pout))) return fail(rc, e->err);
+        }
+        return HX_OK;
+    }
+};
+
+extern "C" {
+
+int hx_index_create(hx_engine *e, int m, int ef_construction, hx_index **out)
+{
+    if (!e || !out) return HX_E_ARG;
+    *out = nullptr;
+    // options.rs:203-225 ranges; build.rs:865-867 ef_construction >= 2m
+    if (m < 2 || m > 100) return e->fail(HX_E_ARG, "m must be between 2 and 100");
+    if (ef_construction < 4 || ef_construction > 1000) return e->fail(HX_E_ARG, "ef_construction must be between 4 and 1000");
+    if (ef_construction < 2 * m) return e->fail(HX_E_ARG, "ef_construction must be greater than or equal to 2 * m");
+    hx_index *ix = new (std::nothrow) hx_index();
+    if (!ix) return e->fail(HX_E_NOMEM, "out of host memory");
+    ix->e = e; ix->g.m = m; ix->efc = ef_construction;
+    int nt = (int)std::thread::hardware_concurrency(); if (nt <= 0) nt = 4; if (nt > 16) nt = 16;
+    ix->n_threads = nt; ix->pool.reset(new Pool(nt - 1));
+    *out = ix;
+    return HX_OK;
+}
+
+int hx_index_destroy(hx_index *ix) { delete ix; return HX_OK; }
+const char *hx_index_last_error(const hx_index *ix) { return ix ? ix->err.c_str() : ""; }
+
+int hx_index_set_threads(hx_index *ix, int n_threads)
+{
+    if (!ix || n_threads < 1 || n_threads > 256) return HX_E_ARG;
+    ix->n_threads = n_threads; ix->pool.reset(new Pool(n_threads - 1));
+    return HX_OK;
+}
+
+// types/hnsw.rs:337-349 with BLCKSZ 8192: (8192 - 24 - 8 - 4 - 4) / 6 / m - 2, capped at 255
+static int max_level_for(int m) { int v = (8192 - 24 - 8 - 4 - 4) / 6 / m - 2; return v < 255 ? v : 255; }
+
+int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids,
+                    uint32_t batch, uint32_t *elem_out)
+{
+    if (!ix) return HX_E_ARG;
+    if (n == 0) return HX_OK;
+    if (!levels || !tids) return ix->fail(HX_E_ARG, "NULL argument");
+    Graph &g = ix->g;
+    if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
+    if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
+    if (batch == 0) batch = 1;
+    const int mxl = max_level_for(g.m);
+    uint32_t done = 0;
+    while (done < n) {
+        uint32_t b = std::min(batch, n - done);
+        // the very first element has nothing to search (build.rs:526-529)
+        if (g.entry < 0) {
+            int lv = std::min(levels[done], mxl); if (lv < 0) lv = 0;
+            uint32_t id = g.add(lv);
+            g.entry = id; g.tids[id][0] = tids[done]; g.ntids[id] = 1;
+            if (elem_out) elem_out[done] = id;
+            done++;
+            continue;
+        }
+        const uint32_t base = g.size();
+        const uint32_t entry = (uint32_t)g.entry; const int entry_level = g.level[entry];
+        std::vector<std::unique_ptr<InsertTask>> its(b);
+        std::vector<LsTask *> tasks(b);
+        for (uint32_t i = 0; i < b; i++) {
+            int lv = std::min(levels[done + i], mxl); if (lv < 0) lv = 0;
+            uint32_t id = g.add(lv);
+            its[i].reset(new InsertTask());
+            InsertTask &t = *its[i];
+            t.g = &g; t.id = id; t.new_level = lv; t.entry = entry; t.entry_level = entry_level; t.efc = ix->efc;
+            tasks[i] = &t;
+        }
+        int rc = ix->run_lockstep(tasks);
+        if (rc) return rc;
+        for (uint32_t i = 0; i < b; i++) {                      // elements[new_idx].neighbors[lc].items = neighbors (mod.rs:422)
+            InsertTask &t = *its[i];
+            for (int lc = 0; lc <= t.new_level; lc++) {
+                Cand *lst = g.list(t.id, lc);
+                for (size_t k = 0; k < t.nb[lc].size(); k++) lst[k] = t.nb[lc][k];
+                g.cnt(t.id, lc) = (uint16_t)t.nb[lc].size();
+            }
+            ix->counters[1] += t.n_dist; ix->counters[2] += t.n_pair;
+        }
+        // duplicate detection (build.rs:482-512): byte-compare the leading zero-distance layer-0 neighbours
+        std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0);
+        for (uint32_t i = 0; i < b; i++) {
+            const uint32_t id = base + i; const Cand *l0 = g.list(id, 0);
+            for (uint16_t k = 0; k < g.cnt(id, 0); k++) { if (l0[k].d != 0.0f) break; da.push_back(id); db.push_back(l0[k].id); }
+            dstart[i + 1] = (uint32_t)da.size();
+        }
+        std::vector<uint8_t> deq(da.size());
+        if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
+        std::vector<BackOp> ops;
+        for (uint32_t i = 0; i < b; i++) {
+            const uint32_t id = base + i;
+            int64_t dup = -1;
+            for (uint32_t k = dstart[i]; k < dstart[i + 1]; k++)
+                if (deq[k] && g.ntids[db[k]] < HEAPTIDS && g.level[db[k]] >= 0) { dup = db[k]; break; }
+            if (dup >= 0) {                                     // merge into the existing element; this row becomes a tombstone
+                g.tids[dup][g.ntids[dup]++] = tids[done + i];
+                for (int lc = 0; lc <= g.level[id]; lc++) g.cnt(id, lc) = 0;
+                g.level[id] = -1 - g.level[id];
+                if (elem_out) elem_out[done + i] = (uint32_t)dup;
+                continue;
+            }
+            for (int lc = g.level[id]; lc >= 0; lc--) {         // update_neighbor_connections order (mod.rs:451-458)
+                const Cand *lst = g.list(id, lc);
+                for (uint16_t k = 0; k < g.cnt(id, lc); k++) ops.push_back(BackOp{lst[k].id, lc, id, lst[k].d});
+            }
+            if (g.level[id] > g.level[g.entry]) g.entry = id;   // build.rs:523-525
+            g.tids[id][0] = tids[done + i]; g.ntids[id] = 1;
+            if (elem_out) elem_out[done + i] = id;
+        }
+        // group back-links per (target, layer), keeping insertion order inside a group
+        std::stable_sort(ops.begin(), ops.end(), [](const BackOp &a, const BackOp &c) { return a.target != c.target ? a.target < c.target : a.layer < c.layer; });
+        std::vector<std::unique_ptr<BacklinkTask>> bts; std::vector<LsTask *> btasks;
+        for (size_t s = 0; s < ops.size();) {
+            size_t t = s; while (t < ops.size() && ops[t].target == ops[s].target && ops[t].layer == ops[s].layer) t++;
+            bts.emplace_back(new BacklinkTask());
+            BacklinkTask &bt = *bts.back();
+            bt.g = &g; bt.target = ops[s].target; bt.layer = ops[s].layer; bt.ops.assign(ops.begin() + s, ops.begin() + t);
+            btasks.push_back(&bt);
+            s = t;
+        }
+        if ((rc = ix->run_lockstep(btasks))) return rc;
+        for (auto &bt : bts) ix->counters[3] += bt->n_pair;
+        done += b;
+    }
+    return HX_OK;
+}
+
+uint32_t hx_index_size(const hx_index *ix) { return ix ? ix->g.size() : 0; }
+int64_t hx_index_entry(const hx_index *ix) { return ix ? ix->g.entry : -1; }
+int hx_index_level(const hx_index *ix, uint32_t elem) { if (!ix || elem >= ix->g.size()) return HX_E_ARG - 1000; return ix->g.level[elem]; }
+
+int hx_index_neighbors(const hx_index *ix, uint32_t elem, int layer, uint32_t *ids_out, float *dist_out)
+{
+    if (!ix || elem >= ix->g.size()) return HX_E_ARG;
+    const Graph &g = ix->g;
+    const int lv = g.level[elem] < 0 ? -1 - g.level[elem] : g.level[elem];
+    if (layer < 0 || layer > lv) return HX_E_ARG;
+    const Cand *l = g.list(elem, layer); const uint16_t n = g.cnt(elem, layer);
+    for (uint16_t k = 0; k < n; k++) { if (ids_out) ids_out[k] = l[k].id; if (dist_out) dist_out[k] = l[k].d; }
+    return n;
+}
+
+int hx_index_heaptids(const hx_index *ix, uint32_t elem, int64_t *tids_out)
+{
+    if (!ix || elem >= ix->g.size()) return HX_E_ARG;
+    const int n = ix->g.ntids[elem];
+    for (int k = 0; k < n; k++) if (tids_out) tids_out[k] = ix->g.tids[elem][k];
+    return n;
+}
+
+int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t count, const uint32_t *ids, const float *dist)
+{
+    if (!ix || elem >= ix->g.size()) return HX_E_ARG;
+    Graph &g = ix->g;
+    if (layer < 0 || g.level[elem] < layer || count > (uint32_t)g.lm(layer) || (count && (!ids || !dist))) return ix->fail(HX_E_ARG, "bad neighbour list");
+    Cand *l = g.list(elem, layer);
+    for (uint32_t k = 0; k < count; k++) l[k] = Cand{dist[k], ids[k]};
+    g.cnt(elem, layer) = (uint16_t)count;
+    return HX_OK;
+}
+
+int hx_index_counters(const hx_index *ix, uint64_t counters_out[8])
+{
+    if (!ix || !counters_out) return HX_E_ARG;
+    memcpy(counters_out, ix->counters, sizeof ix->counters);
+    return HX_OK;
+}
+
+static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, int64_t max_scan_tuples, uint32_t limit,
+                       const uint8_t *filter, uint64_t n_filter, int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out)
+{
+    if (!ix) return HX_E_ARG;
+    if (nq == 0) return HX_OK;
+    if (!tids_out || !counts_out) return ix->fail(HX_E_ARG, "NULL argument");
+    if (ef_search < 1 || ef_search > 1000) return ix->fail(HX_E_ARG, "hnsw.ef_search must be between 1 and 1000");   // options.rs:156-166
+    if (nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
+    std::vector<std::unique_ptr<QueryTask>> qs(nq); std::vector<LsTask *> tasks(nq);
+    for (uint32_t q = 0; q < nq; q++) {
+        qs[q].reset(new QueryTask());
+        QueryTask &t = *qs[q];
+        t.g = &ix->g; t.slot = q; t.ef_search = ef_search; t.mode = mode; t.max_scan_tuples = max_scan_tuples; t.limit = limit;
+        t.filter = filter; t.n_filter = n_filter;
+        tasks[q] = &t;
+    }
+    int rc = ix->run_lockstep(tasks);
+    if (rc) return rc;
+    for (uint32_t q = 0; q < nq; q++) {
+        QueryTask &t = *qs[q];
+        const uint32_t c = (uint32_t)t.out_tid.size();
+        counts_out[q] = c;
+        for (uint32_t k = 0; k < c; k++) {
+            tids_out[(size_t)q * limit + k] = t.out_tid[k];
+            if (dist_out) dist_out[(size_t)q * limit + k] = t.out_d[k];
+            if (elems_out) elems_out[(size_t)q * limit + k] = t.out_elem[k];
+        }
+        ix->counters[4] += t.n_dist;
+    }
+    return HX_OK;
+}
+
+int hx_index_search(hx_index *ix, uint32_t nq, uint32_t ef_search, uint32_t k,
+                    int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out)
+{
+    return search_impl(ix, nq, ef_search, 0, 0, k, nullptr, 0, tids_out, dist_out, elems_out, counts_out);
+}
+
+int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, int64_t max_scan_tuples,
+                              uint32_t limit, const uint8_t *filter_pass, uint64_t n_filter,
+                              int64_t *tids_out, float *dist_out, uint32_t *counts_out)
+{
+    if (mode != 1 && mode != 2) return ix ? ix->fail(HX_E_ARG, "mode must be 1 (relaxed_order) or 2 (strict_order)") : HX_E_ARG;
+    if (max_scan_tuples < 1) return ix->fail(HX_E_ARG, "hnsw.max_scan_tuples must be at least 1");
+    return search_impl(ix, nq, ef_search, mode, max_scan_tuples, limit, filter_pass, n_filter, tids_out, dist_out, nullptr, counts_out);
+}
+
+} // extern "C"
