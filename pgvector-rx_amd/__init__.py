@@ -8,4 +8,4 @@ from .binding import (  # noqa: F401
     BIT, F16, F32, HAMMING, JACCARD, L1, L2SQ, NEG_IP, QUERY_SLOT,
     Engine, HxError, Index, lib, lib_path,
 )
-from .levels import draw_levels, max_level  # noqa: F401
+from .levels import batch_schedule, draw_levels, max_level  # noqa: F401

@@ -182,14 +182,19 @@ k_dist_groups(const uint8_t *__restrict__ rows, const uint8_t *__restrict__ quer
 
 // =================================================================================================
 // K2: many small pair blocks (select_neighbors / back-link pruning operands).
-//   One 512-thread workgroup per slab of <= 512 pairs of one group.  The group's <= 64 rows are staged
-//   through LDS one 1 KiB chunk at a time; each wavefront owns 64 pairs, one f32 accumulator per pair in
-//   registers, and for every pair reads both 16-byte fragments from LDS (conflict-free, contiguous).
+//   One 512-thread workgroup per slab of <= HX_PAIR_SLAB pairs of one group (a 33-row back-link block is
+//   exactly one slab).  The group's <= 64 rows move HBM -> registers -> LDS one 1 KiB chunk at a time,
+//   double-buffered: while the waves compute on chunk c out of LDS buffer c&1, their global loads for
+//   chunk c+1 are already in flight (one barrier per chunk).  Each wavefront owns HX_PAIRS_PER_WAVE
+//   consecutive pairs, one f32 accumulator per pair in registers, walks (i,j) with scalar arithmetic and
+//   reads both 16-byte fragments of a pair from LDS (contiguous, conflict-free).
 //   Same canonical order as K1, so d(a,b) is the same bits whichever kernel produced it.
 //   LDS/VALU-bound, not HBM-bound: each row is fetched once per slab and reused for up to 63 pairs.
 // =================================================================================================
 #define HX_PAIR_WG 512
-#define HX_PAIRS_PER_WAVE 64
+#define HX_PAIR_WAVES 8
+#define HX_PAIRS_PER_WAVE 66
+#define HX_PAIR_SLAB (HX_PAIR_WAVES * HX_PAIRS_PER_WAVE)   /* 528 = 33*32/2 */
 
 __device__ __forceinline__ void tri_decode(uint32_t p, uint32_t &i, uint32_t &j)
 {   // p = i*(i-1)/2 + j, j < i
@@ -199,8 +204,10 @@ __device__ __forceinline__ void tri_decode(uint32_t p, uint32_t &i, uint32_t &j)
     i = ii; j = p - ii * (ii - 1) / 2;
 }
 
-template <class OP>
-__global__ void __launch_bounds__(HX_PAIR_WG)
+// STAGE = rows a wave stages per chunk (>= ceil(rows of the largest group / 8)); MINW = waves per SIMD asked of
+// the register allocator (4 = two workgroups per CU).
+template <class OP, int STAGE, int MINW>
+__global__ void __launch_bounds__(HX_PAIR_WG, MINW)
 k_pair_groups(const uint8_t *__restrict__ rows, uint32_t pitch,
               const uint32_t *__restrict__ pg_off, const uint16_t *__restrict__ pg_na,
               const uint16_t *__restrict__ pg_nb, const uint32_t *__restrict__ pids,
@@ -208,55 +215,76 @@ k_pair_groups(const uint8_t *__restrict__ rows, uint32_t pitch,
               float *__restrict__ out, uint32_t lds_rows)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint32_t *ptab = (uint32_t *)(lds + (size_t)lds_rows * 1024u);
     const uint32_t g = wg_tab[2 * blockIdx.x], p0 = wg_tab[2 * blockIdx.x + 1];
     const uint32_t na = pg_na[g], nb = pg_nb[g], R = na + nb;
     const uint32_t *ids = pids + pg_off[g];
     const uint32_t P = nb ? na * nb : na * (na - 1) / 2;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    {
-        uint32_t p = p0 + threadIdx.x, i = 0, j = 0;
-        if (p < P) {
-            if (nb) { i = p / nb; j = na + p % nb; }
-            else tri_decode(p, i, j);
-        }
-        ptab[threadIdx.x] = i | (j << 16);
-    }
-    const uint32_t npw = P - p0 < HX_PAIR_WG ? P - p0 : HX_PAIR_WG;       // pairs of this slab
-    const bool active = wave * HX_PAIRS_PER_WAVE < npw;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t buf_bytes = lds_rows * 1024u;
+
+    // first pair of this wave (wave-uniform)
+    const uint32_t pw0 = p0 + wave * HX_PAIRS_PER_WAVE;
+    uint32_t i0 = 0, j0 = 0;
+    if (pw0 < P) { if (nb) { i0 = pw0 / nb; j0 = pw0 % nb; } else tri_decode(pw0, i0, j0); }
+    i0 = __builtin_amdgcn_readfirstlane(i0); j0 = __builtin_amdgcn_readfirstlane(j0);
+    const bool active = pw0 < P;
+
+    // rows this wave stages: wave, wave+8, ...
+    uint32_t rid[STAGE];
+#pragma unroll
+    for (int t = 0; t < STAGE; t++) { const uint32_t r = wave + t * HX_PAIR_WAVES; rid[t] = r < R ? ids[r] : 0u; }
 
     typename OP::acc_t acc[HX_PAIRS_PER_WAVE];
 #pragma unroll
     for (int s = 0; s < HX_PAIRS_PER_WAVE; s++) OP::init(acc[s]);
 
-    for (uint32_t c0 = 0; c0 < pitch; c0 += 1024u) {
-        __syncthreads();
-        for (uint32_t r = wave; r < R; r += HX_PAIR_WG / 64) {
-            const uint32_t off = c0 + lane * 16u;
+    u4 pre[STAGE];
+    auto prefetch = [&](uint32_t c0) {
+        const uint32_t off = c0 + lane * 16u;
+#pragma unroll
+        for (int t = 0; t < STAGE; t++) {
             u4 v = {0u, 0u, 0u, 0u};
-            if (off < pitch) v = *(const u4 *)(rows + (size_t)ids[r] * pitch + off);
-            *(u4 *)(lds + r * 1024u + lane * 16u) = v;
+            if (wave + t * HX_PAIR_WAVES < R && off < pitch) v = *(const u4 *)(rows + (size_t)rid[t] * pitch + off);
+            pre[t] = v;
+        }
+    };
+    prefetch(0);
+    uint32_t bufsel = 0;
+    for (uint32_t c0 = 0; c0 < pitch; c0 += 1024u, bufsel ^= 1u) {
+        uint8_t *buf = lds + bufsel * buf_bytes;
+#pragma unroll
+        for (int t = 0; t < STAGE; t++) {
+            const uint32_t r = wave + t * HX_PAIR_WAVES;
+            if (r < R) *(u4 *)(buf + r * 1024u + lane * 16u) = pre[t];
         }
         __syncthreads();
+        if (c0 + 1024u < pitch) prefetch(c0 + 1024u);
         if (active) {
+            uint32_t i = i0, j = j0;
 #pragma unroll
             for (int s = 0; s < HX_PAIRS_PER_WAVE; s++) {
-                const uint32_t pt = __builtin_amdgcn_readfirstlane(ptab[wave * HX_PAIRS_PER_WAVE + s]);
-                const u4 a = *(const u4 *)(lds + (pt & 0xffffu) * 1024u + lane * 16u);
-                const u4 b = *(const u4 *)(lds + (pt >> 16) * 1024u + lane * 16u);
+                const uint32_t ra = i < na ? i : na - 1u;            // pairs past P re-read a valid row; never stored
+                const uint32_t rb = nb ? na + j : j;
+                const u4 a = *(const u4 *)(buf + ra * 1024u + lane * 16u);
+                const u4 b = *(const u4 *)(buf + rb * 1024u + lane * 16u);
                 OP::add(acc[s], a, b);
+                j++;
+                if (j == (nb ? nb : i)) { i++; j = 0; }
             }
         }
     }
     if (!active) return;
-    float res = 0.0f;
+    float res0 = 0.0f, res1 = 0.0f;
 #pragma unroll
     for (int s = 0; s < HX_PAIRS_PER_WAVE; s++) {
         float d = OP::template finish<64>(acc[s]);
-        if (lane == (uint32_t)s) res = d;
+        if (s < 64) { if (lane == (uint32_t)s) res0 = d; }
+        else { if (lane == (uint32_t)(s - 64)) res1 = d; }
     }
-    const uint32_t p = p0 + wave * HX_PAIRS_PER_WAVE + lane;
-    if (p < P) out[pg_out_off[g] + p] = res;
+    const uint64_t ob = pg_out_off[g];
+    if (pw0 + lane < P) out[ob + pw0 + lane] = res0;
+    if (lane < HX_PAIRS_PER_WAVE - 64 && pw0 + 64 + lane < P) out[ob + pw0 + 64 + lane] = res1;
 }
 
 // =================================================================================================
@@ -355,20 +383,27 @@ static void launch_dist(hx_engine *e, uint32_t n_groups)
     }
 }
 
-template <class OP>
-static hipError_t launch_pair(hx_engine *e, uint32_t n_wgs, uint32_t lds_rows)
+template <class OP, int STAGE, int MINW>
+static hipError_t launch_pair_v(hx_engine *e, uint32_t n_wgs, uint32_t lds_rows)
 {
     const HxChannel &c = e->ch;
-    const size_t lds = (size_t)lds_rows * 1024u + HX_PAIR_WG * 4u;
+    const size_t lds = 2 * (size_t)lds_rows * 1024u;
     static thread_local size_t attr_set = 0;
     if (lds > 65536 && attr_set < lds) {
-        hipError_t s = hipFuncSetAttribute((const void *)k_pair_groups<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        hipError_t s = hipFuncSetAttribute((const void *)k_pair_groups<OP, STAGE, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         if (s != hipSuccess) return s;
         attr_set = 160 * 1024;
     }
-    hipLaunchKernelGGL((k_pair_groups<OP>), dim3(n_wgs), dim3(HX_PAIR_WG), lds, e->stream, e->d_rows, (uint32_t)e->pitch,
+    hipLaunchKernelGGL((k_pair_groups<OP, STAGE, MINW>), dim3(n_wgs), dim3(HX_PAIR_WG), lds, e->stream, e->d_rows, (uint32_t)e->pitch,
                        c.d_pg_off, c.d_pg_na, c.d_pg_nb, c.d_pids, c.d_pg_out_off, c.d_wg_tab, c.d_pout, lds_rows);
     return hipGetLastError();
+}
+template <class OP>
+static hipError_t launch_pair(hx_engine *e, uint32_t n_wgs, uint32_t lds_rows)
+{
+    // <= 40 rows per group (the (2m+1)-row back-link blocks at m <= 19): 5 staged rows per wave
+    if (lds_rows <= 40) return launch_pair_v<OP, 5, 2>(e, n_wgs, lds_rows);
+    return launch_pair_v<OP, 8, 2>(e, n_wgs, lds_rows);
 }
 
 #define HX_DISPATCH(e, CALL_F32, CALL_F16, CALL_HAM, CALL_JAC)                               \
@@ -430,8 +465,8 @@ int hx_engine::ensure_pair_capacity(size_t groups, size_t ids, size_t outs)
         if ((rc = grow_pinned(this, ch.h_pout, ch.d_pout, n))) return rc;
         ch.cap_pout = n;
     }
-    // worst case one workgroup per HX_PAIR_WG outputs plus one per group
-    size_t wgs = outs / HX_PAIR_WG + groups + 1;
+    // worst case one workgroup per HX_PAIR_SLAB outputs plus one per group
+    size_t wgs = outs / HX_PAIR_SLAB + groups + 1;
     if (wgs > ch.cap_wg) {
         size_t n = std::max<size_t>(wgs, ch.cap_wg * 2) + 64;
         if ((rc = grow_pinned(this, ch.h_wg_tab, ch.d_wg_tab, 2 * n))) return rc;
@@ -473,7 +508,7 @@ int hx_engine::run_pair(uint32_t n_groups, uint32_t n_ids, uint64_t n_out)
         if (na + nb > HX_PAIR_MAX_ROWS) return fail(HX_E_ARG, "pair group exceeds HX_PAIR_MAX_ROWS");
         uint32_t P = nb ? na * nb : na * (na - 1) / 2;
         lds_rows = std::max(lds_rows, na + nb);
-        for (uint32_t p0 = 0; p0 < P; p0 += HX_PAIR_WG) {
+        for (uint32_t p0 = 0; p0 < P; p0 += HX_PAIR_SLAB) {
             if (n_wgs >= ch.cap_wg) return fail(HX_E_STATE, "pair workgroup table overflow");
             ch.h_wg_tab[2 * n_wgs] = g; ch.h_wg_tab[2 * n_wgs + 1] = p0; n_wgs++;
         }

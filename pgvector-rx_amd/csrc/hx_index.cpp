@@ -646,15 +646,19 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
     const int mxl = max_level_for(g.m);
     uint32_t done = 0;
     while (done < n) {
-        uint32_t b = std::min(batch, n - done);
-        // the very first element has nothing to search (build.rs:526-529)
+        // ramp-up: a batch never exceeds 1/8 of the graph it searches, so early batches (which would be a
+        // large share of a tiny graph and cannot see each other) stay small.  Same rule as
+        // pgvector-rx_amd/levels.py:batch_schedule, which the oracle-side tests follow.
+        uint32_t b = std::min(std::min(batch, n - done), std::max<uint32_t>(1u, g.size() / 8u));
+        // the very first element has nothing to search (build.rs:526-529); it still counts as a member of
+        // its batch so that batch boundaries do not depend on whether the index was empty
         if (g.entry < 0) {
             int lv = std::min(levels[done], mxl); if (lv < 0) lv = 0;
             uint32_t id = g.add(lv);
             g.entry = id; g.tids[id][0] = tids[done]; g.ntids[id] = 1;
             if (elem_out) elem_out[done] = id;
-            done++;
-            continue;
+            done++; b--;
+            if (b == 0) continue;
         }
         const uint32_t base = g.size();
         const uint32_t entry = (uint32_t)g.entry; const int entry_level = g.level[entry];

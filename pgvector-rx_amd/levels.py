@@ -28,3 +28,15 @@ def draw_levels(n, m, seed, start=0):
     u = np.maximum(u, np.finfo(np.float64).tiny)
     lv = np.floor(-np.log(u) * (1.0 / np.log(float(m))))
     return np.minimum(lv, max_level(m)).astype(np.int32)
+
+
+def batch_schedule(size0, n, batch):
+    """Batch sizes hx_index_insert uses for n rows appended to an index of size0 elements with batch cap
+    `batch`: each batch is at most 1/8 of the current graph (hx_index.cpp, ramp-up rule)."""
+    out, size, left = [], size0, n
+    while left > 0:
+        b = min(batch, left, max(1, size // 8))
+        out.append(b)
+        size += b
+        left -= b
+    return out

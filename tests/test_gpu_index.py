@@ -35,8 +35,7 @@ def build_both(dtype, metric, dim, rows, levels, m, efc, batch):
     # schedule, rows merged as duplicates staying behind as tombstones so ids line up)
     oelem = []
     i = 0
-    while i < n:
-        b = min(batch, n - i)
+    for b in hx.batch_schedule(0, n, batch):
         oelem.append(o.insert_batch(rows[i:i + b], levels[i:i + b], tids[i:i + b]))
         i += b
     return e, ix, elem, o, np.concatenate(oelem)
@@ -216,8 +215,9 @@ def test_option_limits():
 
 
 def test_c1_recall_config():
-    """BASELINE configs[0]: 10k x vector(128) L2, m=16, ef_construction=64, ef_search=40 -- recall@10 of the
-    batched device build against exact brute force, and equal to the oracle's recall on a shared prefix."""
+    """BASELINE configs[0]: 10k x vector(128) L2, m=16, ef_construction=64, ef_search=40.  recall@10 of the
+    batched device build vs exact brute force must equal, within sampling noise, the recall of the
+    reference's own schedule and summation order (oracle: sequential inserts, ORC_ORDER_SEQ)."""
     rng = np.random.default_rng(1)
     n, dim, m, efc, efs, k = 10_000, 128, 16, 64, 40, 10
     rows = rng.random((n, dim), dtype=np.float32)
@@ -229,10 +229,16 @@ def test_c1_recall_config():
     ix.insert(0, levels, batch=256)
     e.set_queries(qs)
     tids, d, _, cnt = ix.search(len(qs), efs, k)
-    exact = np.argsort(((rows[None, :, :] - qs[:, None, :]) ** 2).sum(-1) if False else
-                       (qs ** 2).sum(1)[:, None] + (rows ** 2).sum(1)[None, :] - 2.0 * qs @ rows.T, axis=1)[:, :k]
+    d2 = (qs.astype(np.float64) ** 2).sum(1)[:, None] + (rows.astype(np.float64) ** 2).sum(1)[None, :] - 2.0 * qs.astype(np.float64) @ rows.astype(np.float64).T
+    exact = np.argsort(d2, axis=1)[:, :k]
     recall = np.mean([len(set(tids[q, :cnt[q]].tolist()) & set(exact[q].tolist())) / k for q in range(len(qs))])
-    assert recall >= 0.90, recall          # uniform 128-d data is hard; the reference's gates are on 3-d data
+    o = orc.Index(orc.F32, orc.L2SQ, dim, m=m, ef_construction=efc, order=orc.SEQ)
+    o.build(rows, levels, batch=1)
+    ref_recall = np.mean([len(set(t for t, _, _ in o.scan(qs[q], ef_search=efs, limit=k)) & set(exact[q].tolist())) / k for q in range(len(qs))])
+    # uniform 128-d data is a hard case (the reference's own gates use 3-d data): the bar is equality with the
+    # reference, 2000 samples => sigma ~ 0.011
+    assert abs(recall - ref_recall) <= 0.04, (recall, ref_recall)
+    assert recall >= 0.5
     ix.close()
     e.close()
 
