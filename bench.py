@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- HNSW build seconds + QPS@recall@10 on 1M x vector(768) L2 (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one lock-step search pass of the hot path over one batch of --queries synthetic queries
+(get_scan_items + amgettuple semantics, ef_search = --efs, k = 10).  The index those steps run on is built
+first, inside this script, by the batched device build (timed separately -> "build_sec").
+`value` = queries/s over the K timed steps, whole job (N>1: every rank searches its own query batch on its
+replica of the graph; the BUILD is what the ranks share: each lock-step batch of inserts is split over
+the ranks and the results are all-gathered over RCCL, see pgvector-rx_amd/dist_build.py).
+
+Prints ONE JSON line (rank 0).  Inputs are synthetic and resident in HBM before any timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import pgvector_rx_amd as hx  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured-achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--rows", type=int, default=1_000_000)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--m", type=int, default=16)
+    p.add_argument("--efc", type=int, default=200)
+    p.add_argument("--efs", type=int, default=100)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--queries", type=int, default=10_000)
+    p.add_argument("--batch", type=int, default=8192, help="lock-step insert batch cap")
+    p.add_argument("--dist", default="gmm", choices=["gmm", "uniform"])
+    p.add_argument("--threads", type=int, default=0)
+    p.add_argument("--cpu-build-rows", type=int, default=1500)
+    p.add_argument("--cpu-queries", type=int, default=300)
+    p.add_argument("--no-cpu", action="store_true")
+    return p.parse_args()
+
+
+def synth(n, dim, dist, seed, device, centres=None):
+    """U[0,1) or a 1024-centre Gaussian mixture (sigma 0.1), f32, seeded."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if dist == "uniform":
+        return torch.rand((n, dim), generator=g, device=device, dtype=torch.float32), None
+    if centres is None:
+        gc = torch.Generator(device=device)
+        gc.manual_seed(11)
+        centres = torch.rand((1024, dim), generator=gc, device=device, dtype=torch.float32)
+    out = torch.empty((n, dim), device=device, dtype=torch.float32)
+    step = 131072
+    for i in range(0, n, step):
+        b = min(step, n - i)
+        a = torch.randint(0, centres.shape[0], (b,), generator=g, device=device)
+        out[i:i + b] = centres[a] + 0.1 * torch.randn((b, dim), generator=g, device=device, dtype=torch.float32)
+    return out, centres
+
+
+def ground_truth(rows, queries, k):
+    """Exact top-k by squared L2 with torch (plumbing for the recall figure, not the product path)."""
+    rn = (rows * rows).sum(1)
+    out = []
+    step = max(1, int(2e9 // (rows.shape[0] * 4)))
+    for i in range(0, queries.shape[0], step):
+        q = queries[i:i + step]
+        d = rn[None, :] - 2.0 * (q @ rows.T)
+        out.append(torch.topk(d, k, dim=1, largest=False).indices)
+    return torch.cat(out).cpu().numpy()
+
+
+def recall_at_k(tids, cnt, gt, k):
+    hit = 0
+    for q in range(gt.shape[0]):
+        hit += len(set(tids[q, :cnt[q]].tolist()) & set(gt[q].tolist()))
+    return hit / (gt.shape[0] * k)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- synthetic inputs, resident in HBM (identical on every rank: counter-seeded) ----
+    rows, centres = synth(a.rows, a.dim, a.dist, 11, dev)
+    queries, _ = synth(a.queries, a.dim, a.dist, 12 + 1000 * rank, dev, centres)
+    levels = hx.draw_levels(a.rows, a.m, seed=11)
+    torch.cuda.synchronize()
+    eng = hx.Engine(hx.F32, hx.L2SQ, a.dim, a.rows, device=local_rank)
+    eng.append_device(rows.data_ptr(), a.rows)
+    ix = hx.Index(eng, a.m, a.efc)
+    if a.threads:
+        ix.set_threads(a.threads)
+    eng.set_timing(True)
+
+    # ---- build (timed once; barrier + sync on both sides; max over ranks) ----
+    barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        from importlib import import_module
+        import_module("pgvector-rx_amd.dist_build").insert_sharded(ix, 0, levels, a.batch, dist, dev)
+    else:
+        ix.insert(0, levels, batch=a.batch)
+    barrier()
+    build_sec = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([build_sec], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        build_sec = float(t.item())
+    build_stats = {"dist": eng.kernel_stats(0, reset=True), "pair": eng.kernel_stats(1, reset=True)}
+    counters = ix.counters()
+
+    # ---- search steps ----
+    eng.set_queries_device(queries.data_ptr(), a.queries)
+    for _ in range(a.warmup):
+        ix.search(a.queries, a.efs, a.k)
+    eng.kernel_stats(0, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tids, dists, _, cnt = ix.search(a.queries, a.efs, a.k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sstat = eng.kernel_stats(0)
+    qps = world * a.queries * a.steps / dt
+
+    gt = ground_truth(rows, queries, a.k)
+    recall = recall_at_k(tids, cnt, gt, a.k)
+    if world > 1:
+        t = torch.tensor([recall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        recall = float(t.item()) / world
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel of the timed region (query-vs-rows, K1), HIP-event timed on its stream ----
+    row_bytes = a.dim * 4
+    k1_ms = sstat["ms"] / max(1, sstat["launches"])
+    k1_gbps = sstat["units"] * row_bytes / max(sstat["ms"], 1e-9) / 1e6
+    roofline = {"bound": "hbm", "kernel": "k_dist_groups", "achieved": round(k1_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(k1_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+                "launches": sstat["launches"], "avg_launch_ms": round(k1_ms, 4),
+                "distances_per_launch": round(sstat["units"] / max(1, sstat["launches"]), 1), "bytes_per_distance": row_bytes}
+    bd, bp = build_stats["dist"], build_stats["pair"]
+    build_kernels = {
+        "k_dist_groups": {"launches": bd["launches"], "distances": bd["units"], "ms": round(bd["ms"], 1),
+                          "GBps": round(bd["units"] * row_bytes / max(bd["ms"], 1e-9) / 1e6, 1)},
+        "k_pair_groups": {"launches": bp["launches"], "pairs": bp["units"], "ms": round(bp["ms"], 1),
+                          "Gpairs_per_s": round(bp["units"] / max(bp["ms"], 1e-9) / 1e6, 2)},
+    }
+
+    # ---- CPU baseline: the oracle (scalar restatement of the reference) on this box's host cores, 1 thread ----
+    cpu = None
+    if not a.no_cpu and world == 1:
+        from oracle import orc
+        n_cb = min(a.cpu_build_rows, a.rows)
+        host_rows = rows[:n_cb].cpu().numpy()
+        o = orc.Index(orc.F32, orc.L2SQ, a.dim, m=a.m, ef_construction=a.efc, order=orc.SEQ)
+        t0 = time.perf_counter()
+        o.build(host_rows, levels[:n_cb], batch=1)
+        cpu_build = time.perf_counter() - t0
+        del o
+        # search baseline: the scalar scan on the SAME 1M graph the device built
+        all_rows = rows.cpu().numpy()
+        o = orc.Index(orc.F32, orc.L2SQ, a.dim, m=a.m, ef_construction=a.efc, order=orc.SEQ)
+        lv = ix.export_levels()
+        layers = [ix.export_layer(l, with_dist=False) for l in range(int(max(lv.max(), 0)) + 1)]
+        o.load(all_rows, lv, ix.entry, layers)
+        hq = queries[:a.cpu_queries].cpu().numpy()
+        t0 = time.perf_counter()
+        hits = 0
+        for q in range(len(hq)):
+            ids, _ = o.search_topk(hq[q], a.efs, a.k)
+            hits += len(set(ids.tolist()) & set(gt[q].tolist()))
+        cpu_search = time.perf_counter() - t0
+        cpu = {"value": round(len(hq) / cpu_search, 1), "unit": "queries/s", "cores": 1, "kind": "port",
+               "sample": "%d of the same queries, ef_search=%d, scalar oracle (ORC_ORDER_SEQ) scanning the same %d-row graph; "
+                         "omits fmgr/bufmgr/lock overhead so it is faster than the reference itself" % (len(hq), a.efs, a.rows),
+               "recall_at_10": round(hits / (len(hq) * a.k), 4),
+               "build_rows_per_s": round(n_cb / cpu_build, 2),
+               "build_sample": "sequential oracle build of the first %d rows from an empty index: %.1f s" % (n_cb, cpu_build),
+               "host_cpus": os.cpu_count()}
+
+    out = {
+        "metric": "HNSW build sec + QPS@recall@10, 1Mx768 f32 L2",
+        "value": round(qps, 1), "unit": "queries/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1000.0 * dt / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d x vector(%d) L2, m=%d ef_construction=%d, build + search on %d MI355X" % (a.rows, a.dim, a.m, a.efc, world),
+                   "distribution": a.dist, "ef_search": a.efs, "k": a.k, "queries_per_step": a.queries,
+                   "insert_batch_cap": a.batch, "host_threads": a.threads or min(16, os.cpu_count() or 1)},
+        "build_sec": round(build_sec, 2),
+        "build_rows_per_s": round(a.rows / build_sec, 1),
+        "recall_at_10": round(recall, 4),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "build_kernels": build_kernels,
+        "build_distance_evals": {"search": int(counters[1]), "select": int(counters[2]), "backlink": int(counters[3])},
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,12 +159,39 @@ int hx_index_set_threads(hx_index *ix, int n_threads);
 int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels,
                     const int64_t *tids, uint32_t batch, uint32_t *elem_out);
 
+/* The same batch in stages, for sharing one batch between several GPUs of a node (each rank keeps a replica
+ * of rows and graph; DESIGN.md "multi-GPU build"):
+ *   begin  : add the b rows [first_row, first_row+b) as elements (every rank)
+ *   search : find_element_neighbors for members [lo, hi) of the batch (this rank's slice)
+ *   export_new / import_new : serialized neighbour lists of members, exchanged with an all-gather
+ *   links  : duplicate merge + entry point (every rank), then update_neighbor_connections for the lists this
+ *            rank owns (owner = target row id % world)
+ *   export_links / import_links : the updated lists of one owner, exchanged with an all-gather
+ *   end    : closes the batch; elem_out[i] = element holding tid i
+ * hx_index_insert is begin, search(0,b), links(0,1), end. */
+int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids);
+int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi);
+uint64_t hx_index_batch_new_bytes(const hx_index *ix, uint32_t lo, uint32_t hi);
+int hx_index_batch_export_new(const hx_index *ix, uint32_t lo, uint32_t hi, void *buf);
+int hx_index_batch_import_new(hx_index *ix, uint32_t lo, uint32_t hi, const void *buf);
+int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world);
+uint64_t hx_index_batch_links_bytes(const hx_index *ix, uint32_t owner, uint32_t world);
+int hx_index_batch_export_links(const hx_index *ix, uint32_t owner, uint32_t world, void *buf);
+int hx_index_batch_import_links(hx_index *ix, uint32_t owner, uint32_t world, const void *buf);
+int hx_index_batch_end(hx_index *ix, uint32_t *elem_out);
+
 /* graph export (what create_graph_pages/write_neighbor_tuples serialise, build.rs:545-821) */
 uint32_t hx_index_size(const hx_index *ix);
 int64_t hx_index_entry(const hx_index *ix);                   /* -1 = empty */
 int hx_index_level(const hx_index *ix, uint32_t elem);        /* <0 = tombstoned duplicate */
 int hx_index_neighbors(const hx_index *ix, uint32_t elem, int layer, uint32_t *ids_out, float *dist_out); /* returns count */
 int hx_index_heaptids(const hx_index *ix, uint32_t elem, int64_t *tids_out);                              /* returns count (<= 10) */
+/* bulk export: levels (negative = tombstoned duplicate) and one layer's neighbour lists for elements
+ * [first, first+n): ids_out/dist_out are [n][lm] (lm = 2m at layer 0, m above), cnt_out[n]; elements whose level
+ * is below `layer` get cnt 0.  dist_out may be NULL. */
+int hx_index_export_levels(const hx_index *ix, uint32_t first, uint32_t n, int32_t *levels_out);
+int hx_index_export_layer(const hx_index *ix, int layer, uint32_t first, uint32_t n,
+                          uint32_t *ids_out, float *dist_out, uint16_t *cnt_out);
 /* graph import: lets a rank install lists computed elsewhere (multi-GPU exchange) */
 int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t count, const uint32_t *ids, const float *dist);
 

@@ -637,6 +637,27 @@ ORC_API int orc_index_neighbors(const orc_index *x, int i, int layer, int *ids, 
     for (int k = 0; k < n; k++) { if (ids) ids[k] = x->el[i].nbr[layer][k].idx; if (dist) dist[k] = x->el[i].nbr[layer][k].distance; }
     return n;
 }
+/* bulk load of a finished graph (bench.py's cpu_baseline leg times the scalar scan on the same graph the
+ * device built): rows, levels (negative = tombstone), entry; then one call per layer with [n][lm] lists. */
+ORC_API void orc_index_load(orc_index *x, const void *rows, int n, const int *levels, int entry)
+{
+    const uint8_t *r = rows;
+    for (int i = 0; i < n; i++) {
+        int lv = levels[i] < 0 ? -1 - levels[i] : levels[i];
+        int idx = push_element(x, r + (size_t)i * x->row_bytes, lv);
+        if (levels[i] < 0) x->el[idx].merged = 1; else { x->el[idx].ntids = 1; x->el[idx].tids[0] = i; }
+    }
+    x->entry = entry;
+}
+ORC_API void orc_index_set_layer(orc_index *x, int layer, const uint32_t *ids, const float *dist, const uint16_t *cnt)
+{
+    int lm = layer_m(x->m, layer);
+    for (int i = 0; i < x->n; i++) {
+        if (x->el[i].level < layer || x->el[i].merged) continue;
+        x->el[i].ncnt[layer] = cnt[i];
+        for (int k = 0; k < cnt[i]; k++) { x->el[i].nbr[layer][k].idx = (int)ids[(size_t)i * lm + k]; x->el[i].nbr[layer][k].distance = dist ? dist[(size_t)i * lm + k] : 0.0f; }
+    }
+}
 /* test hook mirroring the hand-built graphs of graph/mod.rs:537-584 */
 ORC_API int orc_index_add_raw(orc_index *x, const void *row, int level) { int i = push_element(x, row, level); if (x->entry < 0) x->entry = i; x->el[i].ntids = 1; x->el[i].tids[0] = i; return i; }
 ORC_API void orc_index_link_raw(orc_index *x, int i, int layer, int j, float d)

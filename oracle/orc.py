@@ -59,6 +59,8 @@ def lib():
             "orc_index_counter": (C.c_uint64, [vp, i32]),
             "orc_index_reset_counters": (None, [vp]),
             "orc_index_neighbors": (i32, [vp, i32, i32, vp, vp]),
+            "orc_index_load": (None, [vp, vp, i32, vp, i32]),
+            "orc_index_set_layer": (None, [vp, i32, vp, vp, vp]),
             "orc_index_add_raw": (i32, [vp, vp, i32]),
             "orc_index_link_raw": (None, [vp, i32, i32, i32, f32]),
             "orc_search_layer_raw": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
@@ -212,6 +214,17 @@ class Index:
             lv = self.level(i)
             g.append((lv, [self.neighbors(i, l) for l in range(lv + 1)]))
         return g
+
+    def load(self, rows, levels, entry, layers):
+        """layers: list over layer of (ids [n][lm] uint32, dist [n][lm] float32 or None, cnt [n] uint16)."""
+        rows = as_rows(self.dtype, rows)
+        levels = np.ascontiguousarray(levels, np.int32)
+        lib().orc_index_load(self.h, _p(rows), len(levels), _p(levels), int(entry))
+        for layer, (ids, d, cnt) in enumerate(layers):
+            ids = np.ascontiguousarray(ids, np.uint32)
+            cnt = np.ascontiguousarray(cnt, np.uint16)
+            dp = None if d is None else _p(np.ascontiguousarray(d, np.float32))
+            lib().orc_index_set_layer(self.h, layer, _p(ids), dp, _p(cnt))
 
     # raw hooks mirroring the reference's pure-Rust unit tests
     def add_raw(self, row, level):

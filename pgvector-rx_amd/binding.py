@@ -63,11 +63,23 @@ def lib():
         "hx_index_last_error": (C.c_char_p, [vp]),
         "hx_index_set_threads": (i32, [vp, i32]),
         "hx_index_insert": (i32, [vp, u64, u32, vp, vp, u32, vp]),
+        "hx_index_batch_begin": (i32, [vp, u64, u32, vp, vp]),
+        "hx_index_batch_search": (i32, [vp, u32, u32]),
+        "hx_index_batch_new_bytes": (u64, [vp, u32, u32]),
+        "hx_index_batch_export_new": (i32, [vp, u32, u32, vp]),
+        "hx_index_batch_import_new": (i32, [vp, u32, u32, vp]),
+        "hx_index_batch_links": (i32, [vp, u32, u32]),
+        "hx_index_batch_links_bytes": (u64, [vp, u32, u32]),
+        "hx_index_batch_export_links": (i32, [vp, u32, u32, vp]),
+        "hx_index_batch_import_links": (i32, [vp, u32, u32, vp]),
+        "hx_index_batch_end": (i32, [vp, vp]),
         "hx_index_size": (u32, [vp]),
         "hx_index_entry": (i64, [vp]),
         "hx_index_level": (i32, [vp, u32]),
         "hx_index_neighbors": (i32, [vp, u32, i32, vp, vp]),
         "hx_index_heaptids": (i32, [vp, u32, vp]),
+        "hx_index_export_levels": (i32, [vp, u32, u32, vp]),
+        "hx_index_export_layer": (i32, [vp, i32, u32, u32, vp, vp, vp]),
         "hx_index_set_neighbors": (i32, [vp, u32, i32, u32, vp, vp]),
         "hx_index_counters": (i32, [vp, vp]),
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
@@ -249,6 +261,49 @@ class Index:
         self._ck(lib().hx_index_insert(self.h, first_row, n, _p(levels), _p(tids), batch, _p(out)))
         return out
 
+    # ---- staged batch (multi-GPU build; see dist_build.py) ----
+    def batch_begin(self, first_row, levels, tids):
+        levels = np.ascontiguousarray(levels, np.int32)
+        tids = np.ascontiguousarray(tids, np.int64)
+        self._ck(lib().hx_index_batch_begin(self.h, first_row, len(levels), _p(levels), _p(tids)))
+
+    def batch_search(self, lo, hi):
+        self._ck(lib().hx_index_batch_search(self.h, lo, hi))
+
+    def batch_new_bytes(self, lo, hi):
+        return lib().hx_index_batch_new_bytes(self.h, lo, hi)
+
+    def batch_export_new(self, lo, hi):
+        buf = np.empty(self.batch_new_bytes(lo, hi), np.uint8)
+        self._ck(lib().hx_index_batch_export_new(self.h, lo, hi, _p(buf)))
+        return buf
+
+    def batch_import_new(self, lo, hi, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        assert buf.nbytes == self.batch_new_bytes(lo, hi)
+        self._ck(lib().hx_index_batch_import_new(self.h, lo, hi, _p(buf)))
+
+    def batch_links(self, rank, world):
+        self._ck(lib().hx_index_batch_links(self.h, rank, world))
+
+    def batch_links_bytes(self, owner, world):
+        return lib().hx_index_batch_links_bytes(self.h, owner, world)
+
+    def batch_export_links(self, owner, world):
+        buf = np.empty(self.batch_links_bytes(owner, world), np.uint8)
+        self._ck(lib().hx_index_batch_export_links(self.h, owner, world, _p(buf)))
+        return buf
+
+    def batch_import_links(self, owner, world, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        assert buf.nbytes == self.batch_links_bytes(owner, world)
+        self._ck(lib().hx_index_batch_import_links(self.h, owner, world, _p(buf)))
+
+    def batch_end(self, n):
+        out = np.empty(n, np.uint32)
+        self._ck(lib().hx_index_batch_end(self.h, _p(out)))
+        return out
+
     @property
     def size(self):
         return lib().hx_index_size(self.h)
@@ -272,6 +327,21 @@ class Index:
         t = np.empty(10, np.int64)
         n = lib().hx_index_heaptids(self.h, e, _p(t))
         return t[:n].tolist()
+
+    def export_levels(self, first=0, n=None):
+        n = self.size - first if n is None else n
+        out = np.empty(n, np.int32)
+        self._ck(lib().hx_index_export_levels(self.h, first, n, _p(out)))
+        return out
+
+    def export_layer(self, layer, first=0, n=None, with_dist=True):
+        n = self.size - first if n is None else n
+        lm = 2 * self.m if layer == 0 else self.m
+        ids = np.zeros((n, lm), np.uint32)
+        d = np.zeros((n, lm), np.float32) if with_dist else None
+        cnt = np.zeros(n, np.uint16)
+        self._ck(lib().hx_index_export_layer(self.h, layer, first, n, _p(ids), _p(d), _p(cnt)))
+        return ids, d, cnt
 
     def set_neighbors(self, e, layer, ids, dist):
         ids, dist = _u32(ids), np.ascontiguousarray(dist, np.float32)

@@ -524,8 +524,16 @@ struct Pool {
 } // namespace
 
 // ================================================================================================
+struct BatchState {
+    bool open = false, linked = false;
+    uint32_t base = 0, b = 0, entry = 0; int entry_level = 0;
+    std::vector<int64_t> tids; std::vector<uint32_t> elem; std::vector<uint8_t> searched;
+    std::vector<BackOp> ops; std::vector<std::pair<size_t, size_t>> grp;
+};
+
 struct hx_index {
     hx_engine *e = nullptr;
+    BatchState bs;
     Graph g; int efc = 64;
     std::unique_ptr<Pool> pool; int n_threads = 0;
     uint64_t counters[8] = {0};
@@ -601,6 +609,9 @@ struct hx_index {
     }
 };
 
+// types/hnsw.rs:337-349 with BLCKSZ 8192: (8192 - 24 - 8 - 4 - 4) / 6 / m - 2, capped at 255
+static int max_level_for(int m) { int v = (8192 - 24 - 8 - 4 - 4) / 6 / m - 2; return v < 255 ? v : 255; }
+
 extern "C" {
 
 int hx_index_create(hx_engine *e, int m, int ef_construction, hx_index **out)
@@ -630,8 +641,190 @@ int hx_index_set_threads(hx_index *ix, int n_threads)
     return HX_OK;
 }
 
-// types/hnsw.rs:337-349 with BLCKSZ 8192: (8192 - 24 - 8 - 4 - 4) / 6 / m - 2, capped at 255
-static int max_level_for(int m) { int v = (8192 - 24 - 8 - 4 - 4) / 6 / m - 2; return v < 255 ? v : 255; }
+
+// ---- staged form of one lock-step batch (single GPU: begin, search(0,b), links(0,1), end; several GPUs: every
+// ---- rank holds a replica of rows and graph, searches its slice, prunes the lists it owns, and the serialized
+// ---- lists are all-gathered between the stages -- pgvector-rx_amd/dist_build.py) --------------------------------
+int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids)
+{
+    if (!ix) return HX_E_ARG;
+    if (b == 0 || !levels || !tids) return ix->fail(HX_E_ARG, "empty batch or NULL argument");
+    Graph &g = ix->g; BatchState &bs = ix->bs;
+    if (bs.open) return ix->fail(HX_E_STATE, "a batch is already open");
+    if (g.entry < 0) return ix->fail(HX_E_STATE, "insert the first element with hx_index_insert before opening batches");
+    if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
+    if (first_row + b > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
+    const int mxl = max_level_for(g.m);
+    bs = BatchState();
+    bs.open = true; bs.base = g.size(); bs.b = b; bs.entry = (uint32_t)g.entry; bs.entry_level = g.level[g.entry];
+    bs.tids.assign(tids, tids + b); bs.elem.assign(b, 0); bs.searched.assign(b, 0);
+    for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[i], mxl); if (lv < 0) lv = 0; g.add(lv); }
+    return HX_OK;
+}
+
+// find_element_neighbors for batch members [lo, hi) against the graph as of batch_begin
+int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
+{
+    if (!ix) return HX_E_ARG;
+    BatchState &bs = ix->bs; Graph &g = ix->g;
+    if (!bs.open || lo > hi || hi > bs.b) return ix->fail(HX_E_STATE, "no open batch / bad member range");
+    std::vector<std::unique_ptr<InsertTask>> its(hi - lo);
+    std::vector<LsTask *> tasks(hi - lo);
+    for (uint32_t i = lo; i < hi; i++) {
+        its[i - lo].reset(new InsertTask());
+        InsertTask &t = *its[i - lo];
+        t.g = &g; t.id = bs.base + i; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
+        tasks[i - lo] = &t;
+    }
+    int rc = ix->run_lockstep(tasks);
+    if (rc) return rc;
+    for (uint32_t i = lo; i < hi; i++) {                        // elements[new_idx].neighbors[lc].items = neighbors (mod.rs:422)
+        InsertTask &t = *its[i - lo];
+        for (int lc = 0; lc <= t.new_level; lc++) {
+            Cand *lst = g.list(t.id, lc);
+            for (size_t k = 0; k < t.nb[lc].size(); k++) lst[k] = t.nb[lc][k];
+            g.cnt(t.id, lc) = (uint16_t)t.nb[lc].size();
+        }
+        ix->counters[1] += t.n_dist; ix->counters[2] += t.n_pair;
+        bs.searched[i] = 1;
+    }
+    return HX_OK;
+}
+
+// serialized neighbour lists of the new members [lo, hi): per member, per layer 0..level: u32 count, lm x {u32 id, f32 d}
+static size_t list_bytes(const Graph &g, int layer) { return 4 + (size_t)g.lm(layer) * 8; }
+uint64_t hx_index_batch_new_bytes(const hx_index *ix, uint32_t lo, uint32_t hi)
+{
+    if (!ix || !ix->bs.open || lo > hi || hi > ix->bs.b) return 0;
+    uint64_t n = 0;
+    for (uint32_t i = lo; i < hi; i++) for (int lc = 0; lc <= ix->g.level[ix->bs.base + i]; lc++) n += list_bytes(ix->g, lc);
+    return n;
+}
+static uint8_t *put_list(const Graph &g, uint32_t e, int layer, uint8_t *p)
+{
+    const uint32_t c = g.cnt(e, layer); const Cand *l = g.list(e, layer); const int lm = g.lm(layer);
+    memcpy(p, &c, 4); p += 4;
+    for (int k = 0; k < lm; k++) { Cand x = k < (int)c ? l[k] : Cand{0.0f, 0u}; memcpy(p, &x.id, 4); memcpy(p + 4, &x.d, 4); p += 8; }
+    return p;
+}
+static const uint8_t *get_list(Graph &g, uint32_t e, int layer, const uint8_t *p)
+{
+    uint32_t c; memcpy(&c, p, 4); p += 4; const int lm = g.lm(layer);
+    if (c > (uint32_t)lm) c = (uint32_t)lm;
+    Cand *l = g.list(e, layer);
+    for (int k = 0; k < lm; k++) { if (k < (int)c) { memcpy(&l[k].id, p, 4); memcpy(&l[k].d, p + 4, 4); } p += 8; }
+    g.cnt(e, layer) = (uint16_t)c;
+    return p;
+}
+int hx_index_batch_export_new(const hx_index *ix, uint32_t lo, uint32_t hi, void *buf)
+{
+    if (!ix || !buf || !ix->bs.open || lo > hi || hi > ix->bs.b) return HX_E_ARG;
+    uint8_t *p = (uint8_t *)buf;
+    for (uint32_t i = lo; i < hi; i++) { if (!ix->bs.searched[i]) return HX_E_STATE; for (int lc = 0; lc <= ix->g.level[ix->bs.base + i]; lc++) p = put_list(ix->g, ix->bs.base + i, lc, p); }
+    return HX_OK;
+}
+int hx_index_batch_import_new(hx_index *ix, uint32_t lo, uint32_t hi, const void *buf)
+{
+    if (!ix || !buf || !ix->bs.open || lo > hi || hi > ix->bs.b) return HX_E_ARG;
+    const uint8_t *p = (const uint8_t *)buf;
+    for (uint32_t i = lo; i < hi; i++) { for (int lc = 0; lc <= ix->g.level[ix->bs.base + i]; lc++) p = get_list(ix->g, ix->bs.base + i, lc, p); ix->bs.searched[i] = 1; }
+    return HX_OK;
+}
+
+// duplicate merge + entry-point update (every rank, identical), then back-link pruning of the lists this rank owns
+// (owner of a list = target row id % world)
+int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
+{
+    if (!ix) return HX_E_ARG;
+    BatchState &bs = ix->bs; Graph &g = ix->g;
+    if (!bs.open || world == 0 || rank >= world) return ix->fail(HX_E_STATE, "no open batch / bad rank");
+    for (uint32_t i = 0; i < bs.b; i++) if (!bs.searched[i]) return ix->fail(HX_E_STATE, "batch member without neighbour lists (search or import it first)");
+    const uint32_t b = bs.b, base = bs.base;
+    int rc;
+    // duplicate detection (build.rs:482-512): byte-compare the leading zero-distance layer-0 neighbours
+    std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0);
+    for (uint32_t i = 0; i < b; i++) {
+        const uint32_t id = base + i; const Cand *l0 = g.list(id, 0);
+        for (uint16_t k = 0; k < g.cnt(id, 0); k++) { if (l0[k].d != 0.0f) break; da.push_back(id); db.push_back(l0[k].id); }
+        dstart[i + 1] = (uint32_t)da.size();
+    }
+    std::vector<uint8_t> deq(da.size());
+    if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
+    std::vector<BackOp> &ops = bs.ops; ops.clear();
+    for (uint32_t i = 0; i < b; i++) {
+        const uint32_t id = base + i;
+        int64_t dup = -1;
+        for (uint32_t k = dstart[i]; k < dstart[i + 1]; k++)
+            if (deq[k] && g.ntids[db[k]] < HEAPTIDS && g.level[db[k]] >= 0) { dup = db[k]; break; }
+        if (dup >= 0) {                                     // merge into the existing element; this row becomes a tombstone
+            g.tids[dup][g.ntids[dup]++] = bs.tids[i];
+            for (int lc = 0; lc <= g.level[id]; lc++) g.cnt(id, lc) = 0;
+            g.level[id] = -1 - g.level[id];
+            bs.elem[i] = (uint32_t)dup;
+            continue;
+        }
+        for (int lc = g.level[id]; lc >= 0; lc--) {         // update_neighbor_connections order (mod.rs:451-458)
+            const Cand *lst = g.list(id, lc);
+            for (uint16_t k = 0; k < g.cnt(id, lc); k++) ops.push_back(BackOp{lst[k].id, lc, id, lst[k].d});
+        }
+        if (g.level[id] > g.level[g.entry]) g.entry = id;   // build.rs:523-525
+        g.tids[id][0] = bs.tids[i]; g.ntids[id] = 1;
+        bs.elem[i] = id;
+    }
+    // group back-links per (target, layer), keeping insertion order inside a group
+    std::stable_sort(ops.begin(), ops.end(), [](const BackOp &a, const BackOp &c) { return a.target != c.target ? a.target < c.target : a.layer < c.layer; });
+    bs.grp.clear();
+    for (size_t s = 0; s < ops.size();) {
+        size_t t = s; while (t < ops.size() && ops[t].target == ops[s].target && ops[t].layer == ops[s].layer) t++;
+        bs.grp.push_back({s, t});
+        s = t;
+    }
+    std::vector<std::unique_ptr<BacklinkTask>> bts; std::vector<LsTask *> btasks;
+    for (const auto &gr : bs.grp) {
+        if (ops[gr.first].target % world != rank) continue;
+        bts.emplace_back(new BacklinkTask());
+        BacklinkTask &bt = *bts.back();
+        bt.g = &g; bt.target = ops[gr.first].target; bt.layer = ops[gr.first].layer; bt.ops.assign(ops.begin() + gr.first, ops.begin() + gr.second);
+        btasks.push_back(&bt);
+    }
+    if ((rc = ix->run_lockstep(btasks))) return rc;
+    for (auto &bt : bts) ix->counters[3] += bt->n_pair;
+    bs.linked = true;
+    return HX_OK;
+}
+
+// serialized lists owned by `owner` after the links stage, in (target, layer) order -- every rank derives the same order
+uint64_t hx_index_batch_links_bytes(const hx_index *ix, uint32_t owner, uint32_t world)
+{
+    if (!ix || !ix->bs.open || !ix->bs.linked || world == 0) return 0;
+    uint64_t n = 0;
+    for (const auto &gr : ix->bs.grp) if (ix->bs.ops[gr.first].target % world == owner) n += list_bytes(ix->g, ix->bs.ops[gr.first].layer);
+    return n;
+}
+int hx_index_batch_export_links(const hx_index *ix, uint32_t owner, uint32_t world, void *buf)
+{
+    if (!ix || !buf || !ix->bs.open || !ix->bs.linked || world == 0) return HX_E_ARG;
+    uint8_t *p = (uint8_t *)buf;
+    for (const auto &gr : ix->bs.grp) { const BackOp &o = ix->bs.ops[gr.first]; if (o.target % world == owner) p = put_list(ix->g, o.target, o.layer, p); }
+    return HX_OK;
+}
+int hx_index_batch_import_links(hx_index *ix, uint32_t owner, uint32_t world, const void *buf)
+{
+    if (!ix || !buf || !ix->bs.open || !ix->bs.linked || world == 0) return HX_E_ARG;
+    const uint8_t *p = (const uint8_t *)buf;
+    for (const auto &gr : ix->bs.grp) { const BackOp &o = ix->bs.ops[gr.first]; if (o.target % world == owner) p = get_list(ix->g, o.target, o.layer, p); }
+    return HX_OK;
+}
+
+int hx_index_batch_end(hx_index *ix, uint32_t *elem_out)
+{
+    if (!ix) return HX_E_ARG;
+    BatchState &bs = ix->bs;
+    if (!bs.open || !bs.linked) return ix->fail(HX_E_STATE, "batch not linked yet");
+    if (elem_out) memcpy(elem_out, bs.elem.data(), (size_t)bs.b * sizeof(uint32_t));
+    bs = BatchState();
+    return HX_OK;
+}
 
 int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids,
                     uint32_t batch, uint32_t *elem_out)
@@ -640,6 +833,7 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
     if (n == 0) return HX_OK;
     if (!levels || !tids) return ix->fail(HX_E_ARG, "NULL argument");
     Graph &g = ix->g;
+    if (ix->bs.open) return ix->fail(HX_E_STATE, "a staged batch is open");
     if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
     if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
     if (batch == 0) batch = 1;
@@ -660,72 +854,10 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
             done++; b--;
             if (b == 0) continue;
         }
-        const uint32_t base = g.size();
-        const uint32_t entry = (uint32_t)g.entry; const int entry_level = g.level[entry];
-        std::vector<std::unique_ptr<InsertTask>> its(b);
-        std::vector<LsTask *> tasks(b);
-        for (uint32_t i = 0; i < b; i++) {
-            int lv = std::min(levels[done + i], mxl); if (lv < 0) lv = 0;
-            uint32_t id = g.add(lv);
-            its[i].reset(new InsertTask());
-            InsertTask &t = *its[i];
-            t.g = &g; t.id = id; t.new_level = lv; t.entry = entry; t.entry_level = entry_level; t.efc = ix->efc;
-            tasks[i] = &t;
-        }
-        int rc = ix->run_lockstep(tasks);
-        if (rc) return rc;
-        for (uint32_t i = 0; i < b; i++) {                      // elements[new_idx].neighbors[lc].items = neighbors (mod.rs:422)
-            InsertTask &t = *its[i];
-            for (int lc = 0; lc <= t.new_level; lc++) {
-                Cand *lst = g.list(t.id, lc);
-                for (size_t k = 0; k < t.nb[lc].size(); k++) lst[k] = t.nb[lc][k];
-                g.cnt(t.id, lc) = (uint16_t)t.nb[lc].size();
-            }
-            ix->counters[1] += t.n_dist; ix->counters[2] += t.n_pair;
-        }
-        // duplicate detection (build.rs:482-512): byte-compare the leading zero-distance layer-0 neighbours
-        std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0);
-        for (uint32_t i = 0; i < b; i++) {
-            const uint32_t id = base + i; const Cand *l0 = g.list(id, 0);
-            for (uint16_t k = 0; k < g.cnt(id, 0); k++) { if (l0[k].d != 0.0f) break; da.push_back(id); db.push_back(l0[k].id); }
-            dstart[i + 1] = (uint32_t)da.size();
-        }
-        std::vector<uint8_t> deq(da.size());
-        if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
-        std::vector<BackOp> ops;
-        for (uint32_t i = 0; i < b; i++) {
-            const uint32_t id = base + i;
-            int64_t dup = -1;
-            for (uint32_t k = dstart[i]; k < dstart[i + 1]; k++)
-                if (deq[k] && g.ntids[db[k]] < HEAPTIDS && g.level[db[k]] >= 0) { dup = db[k]; break; }
-            if (dup >= 0) {                                     // merge into the existing element; this row becomes a tombstone
-                g.tids[dup][g.ntids[dup]++] = tids[done + i];
-                for (int lc = 0; lc <= g.level[id]; lc++) g.cnt(id, lc) = 0;
-                g.level[id] = -1 - g.level[id];
-                if (elem_out) elem_out[done + i] = (uint32_t)dup;
-                continue;
-            }
-            for (int lc = g.level[id]; lc >= 0; lc--) {         // update_neighbor_connections order (mod.rs:451-458)
-                const Cand *lst = g.list(id, lc);
-                for (uint16_t k = 0; k < g.cnt(id, lc); k++) ops.push_back(BackOp{lst[k].id, lc, id, lst[k].d});
-            }
-            if (g.level[id] > g.level[g.entry]) g.entry = id;   // build.rs:523-525
-            g.tids[id][0] = tids[done + i]; g.ntids[id] = 1;
-            if (elem_out) elem_out[done + i] = id;
-        }
-        // group back-links per (target, layer), keeping insertion order inside a group
-        std::stable_sort(ops.begin(), ops.end(), [](const BackOp &a, const BackOp &c) { return a.target != c.target ? a.target < c.target : a.layer < c.layer; });
-        std::vector<std::unique_ptr<BacklinkTask>> bts; std::vector<LsTask *> btasks;
-        for (size_t s = 0; s < ops.size();) {
-            size_t t = s; while (t < ops.size() && ops[t].target == ops[s].target && ops[t].layer == ops[s].layer) t++;
-            bts.emplace_back(new BacklinkTask());
-            BacklinkTask &bt = *bts.back();
-            bt.g = &g; bt.target = ops[s].target; bt.layer = ops[s].layer; bt.ops.assign(ops.begin() + s, ops.begin() + t);
-            btasks.push_back(&bt);
-            s = t;
-        }
-        if ((rc = ix->run_lockstep(btasks))) return rc;
-        for (auto &bt : bts) ix->counters[3] += bt->n_pair;
+        int rc;
+        if ((rc = hx_index_batch_begin(ix, first_row + done, b, levels + done, tids + done))) return rc;
+        if ((rc = hx_index_batch_search(ix, 0, b)) || (rc = hx_index_batch_links(ix, 0, 1)) ||
+            (rc = hx_index_batch_end(ix, elem_out ? elem_out + done : nullptr))) { ix->bs = BatchState(); return rc; }
         done += b;
     }
     return HX_OK;
@@ -752,6 +884,27 @@ int hx_index_heaptids(const hx_index *ix, uint32_t elem, int64_t *tids_out)
     const int n = ix->g.ntids[elem];
     for (int k = 0; k < n; k++) if (tids_out) tids_out[k] = ix->g.tids[elem][k];
     return n;
+}
+
+int hx_index_export_levels(const hx_index *ix, uint32_t first, uint32_t n, int32_t *levels_out)
+{
+    if (!ix || (!levels_out && n) || (uint64_t)first + n > ix->g.size()) return HX_E_ARG;
+    if (n) memcpy(levels_out, ix->g.level.data() + first, (size_t)n * sizeof(int32_t));
+    return HX_OK;
+}
+
+int hx_index_export_layer(const hx_index *ix, int layer, uint32_t first, uint32_t n, uint32_t *ids_out, float *dist_out, uint16_t *cnt_out)
+{
+    if (!ix || layer < 0 || (n && (!ids_out || !cnt_out)) || (uint64_t)first + n > ix->g.size()) return HX_E_ARG;
+    const Graph &g = ix->g; const size_t lm = (size_t)g.lm(layer);
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t e = first + i;
+        if (g.level[e] < layer) { cnt_out[i] = 0; continue; }
+        const Cand *l = g.list(e, layer); const uint16_t c = g.cnt(e, layer);
+        cnt_out[i] = c;
+        for (uint16_t k = 0; k < c; k++) { ids_out[i * lm + k] = l[k].id; if (dist_out) dist_out[i * lm + k] = l[k].d; }
+    }
+    return HX_OK;
 }
 
 int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t count, const uint32_t *ids, const float *dist)

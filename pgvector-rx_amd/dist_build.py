@@ -1,0 +1,76 @@
+"""Multi-GPU index build: one lock-step batch of inserts shared by the ranks of a node.
+
+The reference builds strictly sequentially on one core (amcanbuildparallel = false, src/index/handler.rs:153-154).
+Here every rank (one process per GPU, torch.distributed, backend "nccl" = RCCL over xGMI) keeps a replica of the
+rows (288 GB of HBM per GPU makes that free) and of the graph, and each batch is split two ways:
+
+  search stage   rank r runs find_element_neighbors for a contiguous slice of the batch; the members' new
+                 neighbour lists are exchanged with ONE all_gather (fixed-size records, padded per rank)
+  links stage    every rank applies duplicate merge / entry-point update identically, then prunes only the
+                 back-link lists it owns (owner = target row id % world); the updated lists are exchanged with
+                 ONE all_gather in an order all ranks derive identically
+
+so the graph after every batch is bit-identical on all ranks and identical to the single-GPU build with the same
+batch schedule.  The only data-path collectives are those two all_gathers per batch.  Batches smaller than
+`min_shard` members are built redundantly on every rank (a collective would cost more than it saves).
+"""
+import numpy as np
+import torch
+
+
+def slice_bounds(b, world):
+    """Contiguous member slices: rank r searches [lo[r], hi[r]) of a batch of b members."""
+    per = -(-b // world)
+    lo = [min(b, r * per) for r in range(world)]
+    hi = [min(b, r * per + per) for r in range(world)]
+    return lo, hi
+
+
+def exchange(payload, sizes, rank, dist, device):
+    """All-gathers one variable-size byte payload per rank (sizes known to every rank without communication).
+    Returns the list of payloads (numpy uint8), own entry included."""
+    world = len(sizes)
+    cap = max(max(sizes), 1)
+    send = torch.zeros(cap, dtype=torch.uint8, device=device)
+    if sizes[rank]:
+        send[:sizes[rank]] = torch.from_numpy(payload).to(device)
+    recv = torch.empty(world * cap, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    host = recv.cpu().numpy()
+    return [host[r * cap:r * cap + sizes[r]] for r in range(world)]
+
+
+def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_shard=256, size_fn=None):
+    """hx_index_insert for rows [first_row, first_row + len(levels)) with every batch shared by the ranks.
+    `ix` exposes the staged batch API of binding.Index (tests drive this with a stand-in object and gloo)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    levels = np.ascontiguousarray(levels, np.int32)
+    n = len(levels)
+    tids = np.arange(first_row, first_row + n, dtype=np.int64) if tids is None else np.ascontiguousarray(tids, np.int64)
+    elems = np.empty(n, np.uint32)
+    done = 0
+    while done < n:
+        size = ix.size
+        b = min(batch, n - done, max(1, size // 8))           # same ramp-up rule as hx_index_insert
+        if ix.entry < 0 or b < min_shard or world == 1:
+            # replicated: every rank performs the identical single-GPU step
+            elems[done:done + b] = ix.insert(first_row + done, levels[done:done + b], tids[done:done + b], batch=b)
+            done += b
+            continue
+        lo, hi = slice_bounds(b, world)
+        ix.batch_begin(first_row + done, levels[done:done + b], tids[done:done + b])
+        ix.batch_search(lo[rank], hi[rank])
+        sizes = [ix.batch_new_bytes(lo[r], hi[r]) for r in range(world)]
+        mine = ix.batch_export_new(lo[rank], hi[rank])
+        for r, buf in enumerate(exchange(mine, sizes, rank, dist, device)):
+            if r != rank and sizes[r]:
+                ix.batch_import_new(lo[r], hi[r], buf)
+        ix.batch_links(rank, world)
+        sizes = [ix.batch_links_bytes(r, world) for r in range(world)]
+        mine = ix.batch_export_links(rank, world)
+        for r, buf in enumerate(exchange(mine, sizes, rank, dist, device)):
+            if r != rank and sizes[r]:
+                ix.batch_import_links(r, world, buf)
+        elems[done:done + b] = ix.batch_end(b)
+        done += b
+    return elems
