@@ -199,6 +199,10 @@ int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t coun
  * [1] search_layer expansions, [2] select_neighbors in find_element_neighbors, [3] back-link pruning, [4] scan */
 int hx_index_counters(const hx_index *ix, uint64_t counters_out[8]);
 
+/* host-side wall time of the lock-step driver since the last reset, seconds: [0] task state machines,
+ * [1] request compaction, [2] request fill, [3] K1 copies+launch+wait, [4] K2 copies+launch+wait, [5] rounds */
+int hx_index_profile(const hx_index *ix, double seconds_out[8], int reset);
+
 /* get_scan_items + amgettuple (scan.rs:458-530, 709-876), iterative_scan = off, for nq queries in
  * lock-step: the queries are the engine's query slots 0..nq-1 (hx_set_queries).  Per query, up to k heap
  * TIDs nearest first with their distances; counts_out[q] = number returned. */

@@ -82,6 +82,7 @@ def lib():
         "hx_index_export_layer": (i32, [vp, i32, u32, u32, vp, vp, vp]),
         "hx_index_set_neighbors": (i32, [vp, u32, i32, u32, vp, vp]),
         "hx_index_counters": (i32, [vp, vp]),
+        "hx_index_profile": (i32, [vp, vp, i32]),
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
         "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
     }
@@ -351,6 +352,11 @@ class Index:
         c = np.zeros(8, np.uint64)
         self._ck(lib().hx_index_counters(self.h, _p(c)))
         return c
+
+    def profile(self, reset=False):
+        p = np.zeros(8, np.float64)
+        self._ck(lib().hx_index_profile(self.h, _p(p), int(reset)))
+        return {"advance_s": p[0], "compact_s": p[1], "fill_s": p[2], "k1_s": p[3], "k2_s": p[4], "rounds": int(p[5])}
 
     def search(self, nq, ef_search, k):
         tids = np.full((nq, k), -1, np.int64)

@@ -417,123 +417,101 @@ static hipError_t launch_pair(hx_engine *e, uint32_t n_wgs, uint32_t lds_rows)
         }                                                                                     \
     } while (0)
 
-template <class T> static int grow_pinned(hx_engine *e, T *&h, T *&d, size_t n)
+static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+int hx_engine::layout_round(const HxRound &r)
 {
-    if (h) { (void)hipHostFree(h); h = nullptr; }
-    if (d) { (void)hipFree(d); d = nullptr; }
-    HX_HIP(e, hipHostMalloc((void **)&h, n * sizeof(T), hipHostMallocDefault));
-    HX_HIP(e, hipMalloc((void **)&d, n * sizeof(T)));
+    HxChannel &c = ch;
+    c.round = r;
+    c.max_wgs = (uint32_t)(r.n_pout / HX_PAIR_SLAB + r.n_pgroups + 1);
+    size_t o = 0;
+    const size_t o_grp_q = o;      o = al16(o + (size_t)r.n_dgroups * 4);
+    const size_t o_grp_off = o;    o = al16(o + ((size_t)r.n_dgroups + 1) * 4);
+    const size_t o_ids = o;        o = al16(o + (size_t)r.n_dids * 4);
+    const size_t o_pg_off = o;     o = al16(o + ((size_t)r.n_pgroups + 1) * 4);
+    const size_t o_pg_out = o;     o = al16(o + (size_t)r.n_pgroups * 8);
+    const size_t o_pg_na = o;      o = al16(o + (size_t)r.n_pgroups * 2);
+    const size_t o_pg_nb = o;      o = al16(o + (size_t)r.n_pgroups * 2);
+    const size_t o_pids = o;       o = al16(o + (size_t)r.n_pids * 4);
+    const size_t o_wg = o;         o = al16(o + (size_t)c.max_wgs * 8);
+    c.req_bytes = o;
+    const size_t o_out = 0, o_pout = al16((size_t)r.n_dids * 4);
+    c.res_bytes = al16(o_pout + (size_t)r.n_pout * 4);
+    if (c.req_bytes > c.cap_req) {
+        size_t n = std::max(c.req_bytes, c.cap_req * 2) + 4096;
+        if (c.h_req) (void)hipHostFree(c.h_req);
+        if (c.d_req) (void)hipFree(c.d_req);
+        c.h_req = c.d_req = nullptr; c.cap_req = 0;
+        HX_HIP(this, hipHostMalloc((void **)&c.h_req, n, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&c.d_req, n));
+        c.cap_req = n;
+    }
+    if (c.res_bytes > c.cap_res) {
+        size_t n = std::max(c.res_bytes, c.cap_res * 2) + 4096;
+        if (c.h_res) (void)hipHostFree(c.h_res);
+        if (c.d_res) (void)hipFree(c.d_res);
+        c.h_res = c.d_res = nullptr; c.cap_res = 0;
+        HX_HIP(this, hipHostMalloc((void **)&c.h_res, n, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&c.d_res, n));
+        c.cap_res = n;
+    }
+#define HX_SUB(T, name, off) c.h_##name = (T *)(c.h_req + (off)); c.d_##name = (T *)(c.d_req + (off))
+    HX_SUB(uint32_t, grp_q, o_grp_q); HX_SUB(uint32_t, grp_off, o_grp_off); HX_SUB(uint32_t, ids, o_ids);
+    HX_SUB(uint32_t, pg_off, o_pg_off); HX_SUB(uint64_t, pg_out_off, o_pg_out); HX_SUB(uint16_t, pg_na, o_pg_na);
+    HX_SUB(uint16_t, pg_nb, o_pg_nb); HX_SUB(uint32_t, pids, o_pids); HX_SUB(uint32_t, wg_tab, o_wg);
+#undef HX_SUB
+    c.h_out = (float *)(c.h_res + o_out); c.d_out = (float *)(c.d_res + o_out);
+    c.h_pout = (float *)(c.h_res + o_pout); c.d_pout = (float *)(c.d_res + o_pout);
     return HX_OK;
 }
 
-int hx_engine::ensure_dist_capacity(size_t groups, size_t ids)
+int hx_engine::run_round()
 {
-    int rc;
-    if (groups + 1 > ch.cap_groups) {
-        size_t n = std::max<size_t>(groups + 1, ch.cap_groups * 2) + 64;
-        if ((rc = grow_pinned(this, ch.h_grp_q, ch.d_grp_q, n))) return rc;
-        if ((rc = grow_pinned(this, ch.h_grp_off, ch.d_grp_off, n))) return rc;
-        ch.cap_groups = n;
-    }
-    if (ids > ch.cap_ids) {
-        size_t n = std::max<size_t>(ids, ch.cap_ids * 2) + 256;
-        if ((rc = grow_pinned(this, ch.h_ids, ch.d_ids, n))) return rc;
-        if ((rc = grow_pinned(this, ch.h_out, ch.d_out, n))) return rc;
-        ch.cap_ids = n;
-    }
-    return HX_OK;
-}
-
-int hx_engine::ensure_pair_capacity(size_t groups, size_t ids, size_t outs)
-{
-    int rc;
-    if (groups + 1 > ch.cap_pgroups) {
-        size_t n = std::max<size_t>(groups + 1, ch.cap_pgroups * 2) + 64;
-        if ((rc = grow_pinned(this, ch.h_pg_off, ch.d_pg_off, n))) return rc;
-        if ((rc = grow_pinned(this, ch.h_pg_na, ch.d_pg_na, n))) return rc;
-        if ((rc = grow_pinned(this, ch.h_pg_nb, ch.d_pg_nb, n))) return rc;
-        if ((rc = grow_pinned(this, ch.h_pg_out_off, ch.d_pg_out_off, n))) return rc;
-        ch.cap_pgroups = n;
-    }
-    if (ids > ch.cap_pids) {
-        size_t n = std::max<size_t>(ids, ch.cap_pids * 2) + 256;
-        if ((rc = grow_pinned(this, ch.h_pids, ch.d_pids, n))) return rc;
-        ch.cap_pids = n;
-    }
-    if (outs > ch.cap_pout) {
-        size_t n = std::max<size_t>(outs, ch.cap_pout * 2) + 1024;
-        if ((rc = grow_pinned(this, ch.h_pout, ch.d_pout, n))) return rc;
-        ch.cap_pout = n;
-    }
-    // worst case one workgroup per HX_PAIR_SLAB outputs plus one per group
-    size_t wgs = outs / HX_PAIR_SLAB + groups + 1;
-    if (wgs > ch.cap_wg) {
-        size_t n = std::max<size_t>(wgs, ch.cap_wg * 2) + 64;
-        if ((rc = grow_pinned(this, ch.h_wg_tab, ch.d_wg_tab, 2 * n))) return rc;
-        ch.cap_wg = n;
-    }
-    return HX_OK;
-}
-
-int hx_engine::run_dist(uint32_t n_groups, uint32_t n_ids)
-{
-    if (n_groups == 0 || n_ids == 0) return HX_OK;
-    HX_HIP(this, hipMemcpyAsync(ch.d_grp_q, ch.h_grp_q, n_groups * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.d_grp_off, ch.h_grp_off, (n_groups + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.d_ids, ch.h_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
-#define F32C(K) launch_dist<OpF32<K>>(this, n_groups)
-#define F16C(K) launch_dist<OpF16<K>>(this, n_groups)
-    HX_DISPATCH(this, F32C, F16C, launch_dist<OpHamming>(this, n_groups), launch_dist<OpJaccard>(this, n_groups));
-#undef F32C
-#undef F16C
-    HX_HIP(this, hipGetLastError());
-    if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.h_out, ch.d_out, n_ids * sizeof(float), hipMemcpyDeviceToHost, stream));
-    HX_HIP(this, hipStreamSynchronize(stream));
-    if (timing) {
-        HX_HIP(this, hipEventElapsedTime(&last_ms, ev0, ev1));
-        stat_dist.launches++; stat_dist.units += n_ids; stat_dist.ms += last_ms;
-    }
-    return HX_OK;
-}
-
-int hx_engine::run_pair(uint32_t n_groups, uint32_t n_ids, uint64_t n_out)
-{
-    if (n_groups == 0 || n_out == 0) return HX_OK;
-    // workgroup table + LDS rows
+    HxChannel &c = ch;
+    const HxRound &r = c.round;
+    const bool do_dist = r.n_dgroups > 0 && r.n_dids > 0;
+    // workgroup table + LDS rows of the pair launch
     uint32_t n_wgs = 0, lds_rows = 1;
-    for (uint32_t g = 0; g < n_groups; g++) {
-        uint32_t na = ch.h_pg_na[g], nb = ch.h_pg_nb[g];
-        if (na + nb > HX_PAIR_MAX_ROWS) return fail(HX_E_ARG, "pair group exceeds HX_PAIR_MAX_ROWS");
-        uint32_t P = nb ? na * nb : na * (na - 1) / 2;
-        lds_rows = std::max(lds_rows, na + nb);
-        for (uint32_t p0 = 0; p0 < P; p0 += HX_PAIR_SLAB) {
-            if (n_wgs >= ch.cap_wg) return fail(HX_E_STATE, "pair workgroup table overflow");
-            ch.h_wg_tab[2 * n_wgs] = g; ch.h_wg_tab[2 * n_wgs + 1] = p0; n_wgs++;
+    if (r.n_pgroups > 0 && r.n_pout > 0) {
+        for (uint32_t g = 0; g < r.n_pgroups; g++) {
+            const uint32_t na = c.h_pg_na[g], nb = c.h_pg_nb[g];
+            if (na + nb > HX_PAIR_MAX_ROWS) return fail(HX_E_ARG, "pair group exceeds HX_PAIR_MAX_ROWS");
+            const uint32_t P = nb ? na * nb : na * (na - 1) / 2;
+            lds_rows = std::max(lds_rows, na + nb);
+            for (uint32_t p0 = 0; p0 < P; p0 += HX_PAIR_SLAB) {
+                if (n_wgs >= c.max_wgs) return fail(HX_E_STATE, "pair workgroup table overflow");
+                c.h_wg_tab[2 * n_wgs] = g; c.h_wg_tab[2 * n_wgs + 1] = p0; n_wgs++;
+            }
         }
     }
-    if (n_wgs == 0) return HX_OK;
-    HX_HIP(this, hipMemcpyAsync(ch.d_pg_off, ch.h_pg_off, (n_groups + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.d_pg_na, ch.h_pg_na, n_groups * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.d_pg_nb, ch.h_pg_nb, n_groups * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.d_pg_out_off, ch.h_pg_out_off, n_groups * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.d_pids, ch.h_pids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.d_wg_tab, ch.h_wg_tab, 2 * n_wgs * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
-    hipError_t ls = hipSuccess;
-#define F32C(K) ls = launch_pair<OpF32<K>>(this, n_wgs, lds_rows)
-#define F16C(K) ls = launch_pair<OpF16<K>>(this, n_wgs, lds_rows)
-    HX_DISPATCH(this, F32C, F16C, ls = launch_pair<OpHamming>(this, n_wgs, lds_rows), ls = launch_pair<OpJaccard>(this, n_wgs, lds_rows));
+    if (!do_dist && n_wgs == 0) return HX_OK;
+    HX_HIP(this, hipMemcpyAsync(c.d_req, c.h_req, c.req_bytes, hipMemcpyHostToDevice, stream));
+    if (do_dist) {
+        if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
+#define F32C(K) launch_dist<OpF32<K>>(this, r.n_dgroups)
+#define F16C(K) launch_dist<OpF16<K>>(this, r.n_dgroups)
+        HX_DISPATCH(this, F32C, F16C, launch_dist<OpHamming>(this, r.n_dgroups), launch_dist<OpJaccard>(this, r.n_dgroups));
 #undef F32C
 #undef F16C
-    HX_HIP(this, ls);
-    if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
-    HX_HIP(this, hipMemcpyAsync(ch.h_pout, ch.d_pout, n_out * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HX_HIP(this, hipGetLastError());
+        if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
+    }
+    if (n_wgs) {
+        if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+        hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_pair<OpF32<K>>(this, n_wgs, lds_rows)
+#define F16C(K) ls = launch_pair<OpF16<K>>(this, n_wgs, lds_rows)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_pair<OpHamming>(this, n_wgs, lds_rows), ls = launch_pair<OpJaccard>(this, n_wgs, lds_rows));
+#undef F32C
+#undef F16C
+        HX_HIP(this, ls);
+        if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    }
+    HX_HIP(this, hipMemcpyAsync(c.h_res, c.d_res, c.res_bytes, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
     if (timing) {
-        HX_HIP(this, hipEventElapsedTime(&last_ms, ev0, ev1));
-        stat_pair.launches++; stat_pair.units += n_out; stat_pair.ms += last_ms;
+        if (do_dist) { HX_HIP(this, hipEventElapsedTime(&last_ms, ev0, ev1)); stat_dist.launches++; stat_dist.units += r.n_dids; stat_dist.ms += last_ms; }
+        if (n_wgs) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_pair.launches++; stat_pair.units += r.n_pout; stat_pair.ms += ms; }
     }
     return HX_OK;
 }
@@ -577,6 +555,8 @@ int hx_create(int device, int dtype, int metric, int dim, uint64_t capacity_rows
     CREATE_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_HIP(hipEventCreate(&e->ev0));
     CREATE_HIP(hipEventCreate(&e->ev1));
+    CREATE_HIP(hipEventCreate(&e->ev2));
+    CREATE_HIP(hipEventCreate(&e->ev3));
     s = hipMalloc((void **)&e->d_rows, e->capacity * e->pitch);
     if (s != hipSuccess) { hx_destroy(e); return create_fail(HX_E_NOMEM, "cannot reserve row store in HBM"); }
     e->cap_queries = 64;
@@ -594,12 +574,14 @@ int hx_destroy(hx_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     HxChannel &c = e->ch;
-    void *hp[] = {c.h_grp_q, c.h_grp_off, c.h_ids, c.h_out, c.h_pg_off, c.h_pids, c.h_wg_tab, c.h_pg_na, c.h_pg_nb, c.h_pg_out_off, c.h_pout};
-    void *dp[] = {c.d_grp_q, c.d_grp_off, c.d_ids, c.d_out, c.d_pg_off, c.d_pids, c.d_wg_tab, c.d_pg_na, c.d_pg_nb, c.d_pg_out_off, c.d_pout, e->d_rows, e->d_queries};
+    void *hp[] = {c.h_req, c.h_res};
+    void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries};
     for (void *p : hp) if (p) (void)hipHostFree(p);
     for (void *p : dp) if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev2) (void)hipEventDestroy(e->ev2);
+    if (e->ev3) (void)hipEventDestroy(e->ev3);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return HX_OK;
@@ -720,11 +702,12 @@ int hx_distances_batch(hx_engine *e, uint32_t n_groups, const uint32_t *group_qu
         else if (q >= e->n_rows) return e->fail(HX_E_ARG, "query row id out of range");
     }
     HX_HIP(e, hipSetDevice(e->device));
-    if ((rc = e->ensure_dist_capacity(n_groups, n_ids))) return rc;
+    HxRound r; r.n_dgroups = n_groups; r.n_dids = n_ids;
+    if ((rc = e->layout_round(r))) return rc;
     memcpy(e->ch.h_grp_q, group_query, n_groups * sizeof(uint32_t));
     memcpy(e->ch.h_grp_off, group_offsets, (n_groups + 1) * sizeof(uint32_t));
     memcpy(e->ch.h_ids, row_ids, n_ids * sizeof(uint32_t));
-    if ((rc = e->run_dist(n_groups, n_ids))) return rc;
+    if ((rc = e->run_round())) return rc;
     memcpy(out, e->ch.h_out, n_ids * sizeof(float));
     return HX_OK;
 }
@@ -764,13 +747,14 @@ int hx_pairwise_many(hx_engine *e, uint32_t n_groups, const uint32_t *group_offs
         n_out = std::max(n_out, out_offsets[g] + P);
     }
     HX_HIP(e, hipSetDevice(e->device));
-    if ((rc = e->ensure_pair_capacity(n_groups, n_ids, n_out))) return rc;
+    HxRound r; r.n_pgroups = n_groups; r.n_pids = n_ids; r.n_pout = n_out;
+    if ((rc = e->layout_round(r))) return rc;
     memcpy(e->ch.h_pg_off, group_offsets, (n_groups + 1) * sizeof(uint32_t));
     memcpy(e->ch.h_pg_na, na, n_groups * sizeof(uint16_t));
     memcpy(e->ch.h_pg_nb, nb, n_groups * sizeof(uint16_t));
     memcpy(e->ch.h_pg_out_off, out_offsets, n_groups * sizeof(uint64_t));
     memcpy(e->ch.h_pids, ids, n_ids * sizeof(uint32_t));
-    if ((rc = e->run_pair(n_groups, n_ids, n_out))) return rc;
+    if ((rc = e->run_round())) return rc;
     memcpy(out, e->ch.h_pout, n_out * sizeof(float));
     return HX_OK;
 }

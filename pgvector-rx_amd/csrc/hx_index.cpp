@@ -30,6 +30,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <chrono>
 
 namespace {
 
@@ -166,6 +167,7 @@ struct LsTask {
     std::vector<PairGroup> pgroups; std::vector<uint32_t> pair_ids;
     // where the scheduler put the results of the last request
     size_t dist_off = 0, pair_out_off = 0;
+    bool fresh = true;
     uint64_t n_dist = 0, n_pair = 0;          // distance evaluations requested by this task
     virtual ~LsTask() {}
     // consumes the results of its previous request (dres/pres point at this task's slices) and either
@@ -192,7 +194,7 @@ struct SearchCore {
     {
         g = gr; ef = ef_; layer = layer_; scan_mode = scan; discarded = disc;
         C.clear(); W.clear(); wlen = 0; pend.clear(); finished = false;
-        if (shared_vis) vis = shared_vis; else { own_vis.reset(ef * 2 + 64); vis = &own_vis; }
+        if (shared_vis) vis = shared_vis; else { own_vis.reset(ef * 8 + 64); vis = &own_vis; }
         for (const Cand &e : ep) {
             if (add_entry_to_visited) vis->test_and_set(e.id);
             C.push(e); W.push(e); wlen++;
@@ -225,7 +227,7 @@ struct SearchCore {
             for (uint16_t k = 0; k < n; k++) {
                 const uint32_t e = nb[k].id;
                 if (vis->test_and_set(e)) continue;                                  // mod.rs:206-209
-                if (g->level[e] < layer) continue;                                   // mod.rs:213-216 (never enters C/W/discarded in scan.rs either)
+                if (layer > 0 && g->level[e] < layer) continue;                      // mod.rs:213-216; at layer 0 every linked element qualifies (tombstones are never linked)
                 pend.push_back(e);
             }
             if (!pend.empty()) return true;
@@ -495,29 +497,44 @@ struct QueryTask : LsTask {
 // tiny persistent thread pool: parallel_for over task indices
 // ------------------------------------------------------------------------------------------------
 struct Pool {
-    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, cv_done;
-    std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}; size_t chunk = 1;
-    uint64_t gen = 0; int busy = 0; bool stop = false;
+    // Persistent workers.  While a lock-step run is in progress (`hot`), workers spin on `epoch` instead of sleeping
+    // on a condition variable: a run issues thousands of short parallel phases back to back and a futex wake-up
+    // (~20-50 us) per phase would dominate them.
+    std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
+    std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0};
+    std::atomic<uint64_t> epoch{0}; std::atomic<int> done{0}; std::atomic<bool> stop{false}, hot{false};
     explicit Pool(int nt) { for (int i = 0; i < nt; i++) th.emplace_back([this] { loop(); }); }
-    ~Pool() { { std::lock_guard<std::mutex> l(mu); stop = true; } cv.notify_all(); for (auto &t : th) t.join(); }
-    void work() { for (;;) { size_t b = next.fetch_add(chunk); if (b >= n) break; size_t e = std::min(n, b + chunk); for (size_t i = b; i < e; i++) fn(i); } }
+    ~Pool() { stop = true; { std::lock_guard<std::mutex> l(mu); } cv.notify_all(); for (auto &t : th) t.join(); }
+    void work() { for (;;) { size_t i = next.fetch_add(1, std::memory_order_relaxed); if (i >= n) break; fn(i); } }
     void loop()
     {
         uint64_t seen = 0;
         for (;;) {
-            { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+            int spins = 0;
+            while (epoch.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+                // brief spin only: the box gives this process a CPU *quota*, so cycles burnt spinning are cycles the
+                // task logic does not get
+                if (hot.load(std::memory_order_relaxed) && spins < 200) { spins++; __builtin_ia32_pause(); continue; }
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait_for(l, std::chrono::milliseconds(200), [&] { return stop.load() || epoch.load() != seen; });
+            }
+            if (stop.load()) return;
+            seen = epoch.load(std::memory_order_acquire);
             work();
-            { std::lock_guard<std::mutex> l(mu); if (--busy == 0) cv_done.notify_one(); }
+            done.fetch_add(1, std::memory_order_release);
         }
     }
+    void set_hot(bool h) { hot = h; if (h) { std::lock_guard<std::mutex> l(mu); } cv.notify_all(); }
+    // runs f(0..count-1) on the workers + the calling thread; items are handed out one at a time (callers pass chunks)
     void parallel_for(size_t count, const std::function<void(size_t)> &f)
     {
         if (count == 0) return;
-        if (th.empty() || count < 64) { for (size_t i = 0; i < count; i++) f(i); return; }
-        { std::lock_guard<std::mutex> l(mu); fn = f; n = count; next = 0; chunk = std::max<size_t>(1, count / (th.size() * 8 + 8)); busy = (int)th.size(); gen++; }
+        if (th.empty() || count == 1) { for (size_t i = 0; i < count; i++) f(i); return; }
+        fn = f; n = count; next.store(0); done.store(0);
+        { std::lock_guard<std::mutex> l(mu); epoch.fetch_add(1, std::memory_order_release); }
         cv.notify_all();
         work();
-        std::unique_lock<std::mutex> l(mu); cv_done.wait(l, [&] { return busy == 0; });
+        for (int spins = 0; done.load(std::memory_order_acquire) != (int)th.size(); spins++) { if (spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield(); }
     }
 };
 
@@ -537,75 +554,104 @@ struct hx_index {
     Graph g; int efc = 64;
     std::unique_ptr<Pool> pool; int n_threads = 0;
     uint64_t counters[8] = {0};
+    std::vector<std::unique_ptr<InsertTask>> insert_pool;      // task objects are reused across batches (their heaps,
+    std::vector<std::unique_ptr<BacklinkTask>> backlink_pool;  // visited tables and request vectors keep their capacity)
+    std::vector<std::unique_ptr<QueryTask>> query_pool;
+    double prof[8] = {0};   // seconds: [0] advance, [1] compact, [2] fill, [3] dist launch+wait, [4] pair launch+wait, [5] rounds
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
 
-    // Runs tasks to completion in lock-step: every round, every live task's request goes into ONE
-    // distance launch and ONE pair launch.
-    int run_lockstep(std::vector<LsTask *> &tasks)
+    // Runs tasks to completion in lock-step: every round, every live task's request goes into ONE distance launch
+    // and ONE pair launch.  At most `window` tasks are live at a time; finished ones are replaced from the rest of
+    // `tasks` (continuous admission keeps the launches full until the tail).
+    struct ChunkSum { size_t alive = 0, dgroups = 0, dids = 0, pgroups = 0, pids = 0, pout = 0; };
+    int run_lockstep(std::vector<LsTask *> &tasks, size_t window = 0)
     {
-        std::vector<LsTask *> live = tasks;
-        std::vector<uint8_t> alive(live.size(), 1);
-        bool first = true;
-        std::vector<size_t> pair_ids_off;
+        if (tasks.empty()) return HX_OK;
+        if (window == 0 || window > tasks.size()) window = tasks.size();
+        std::vector<LsTask *> live(tasks.begin(), tasks.begin() + window), live2;
+        size_t admitted = window;
+        for (LsTask *t : live) t->fresh = true;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        pool->set_hot(true);
+        int rc = HX_OK;
+        std::vector<ChunkSum> sums, base;
+        std::vector<uint8_t> alive;
         while (!live.empty()) {
             const float *dbase = e->ch.h_out, *pbase = e->ch.h_pout;
-            pool->parallel_for(live.size(), [&](size_t i) {
-                LsTask *t = live[i];
-                alive[i] = t->advance(first ? nullptr : dbase + t->dist_off, first ? nullptr : pbase + t->pair_out_off) ? 1 : 0;
-            });
-            first = false;
-            // compact + assign offsets
-            size_t w = 0, n_dgroups = 0, n_dids = 0, n_pgroups = 0, n_pids = 0, n_pout = 0;
-            pair_ids_off.clear();
-            for (size_t i = 0; i < live.size(); i++) {
-                if (!alive[i]) continue;
-                LsTask *t = live[i];
-                t->dist_off = n_dids;
-                if (!t->dist_ids.empty()) { n_dgroups++; n_dids += t->dist_ids.size(); }
-                t->pair_out_off = n_pout;
-                pair_ids_off.push_back(n_pids);
-                size_t idp = 0;
-                for (const PairGroup &pg : t->pgroups) {
-                    n_pgroups++; idp += (size_t)pg.na + pg.nb;
-                    n_pout += pg.nb ? (size_t)pg.na * pg.nb : (size_t)pg.na * (pg.na - 1) / 2;
-                }
-                n_pids += idp;
-                live[w++] = t;
-            }
-            live.resize(w); alive.assign(w, 1);
-            if (live.empty()) break;
-            int rc;
-            if ((rc = e->ensure_dist_capacity(n_dgroups, n_dids))) return fail(rc, e->err);
-            if ((rc = e->ensure_pair_capacity(n_pgroups, n_pids, n_pout))) return fail(rc, e->err);
-            // fill the pinned request arrays (serial prefix for group slots, parallel copy of ids)
-            std::vector<uint32_t> dg_slot(live.size()), pg_slot(live.size());
-            { size_t dg = 0, pg = 0; for (size_t i = 0; i < live.size(); i++) { dg_slot[i] = (uint32_t)dg; pg_slot[i] = (uint32_t)pg; if (!live[i]->dist_ids.empty()) dg++; pg += live[i]->pgroups.size(); } }
-            HxChannel &c = e->ch;
-            pool->parallel_for(live.size(), [&](size_t i) {
-                LsTask *t = live[i];
-                if (!t->dist_ids.empty()) {
-                    const uint32_t s = dg_slot[i];
-                    c.h_grp_q[s] = t->q_sel; c.h_grp_off[s] = (uint32_t)t->dist_off;
-                    memcpy(c.h_ids + t->dist_off, t->dist_ids.data(), t->dist_ids.size() * sizeof(uint32_t));
-                }
-                if (!t->pgroups.empty()) {
-                    size_t ido = pair_ids_off[i], oo = t->pair_out_off; uint32_t s = pg_slot[i];
-                    memcpy(c.h_pids + ido, t->pair_ids.data(), t->pair_ids.size() * sizeof(uint32_t));
+            const size_t nlive = live.size();
+            const size_t csize = std::max<size_t>(16, nlive / ((size_t)n_threads * 6) + 1), nchunks = (nlive + csize - 1) / csize;
+            sums.assign(nchunks, ChunkSum()); alive.assign(nlive, 0);
+            double t0 = now();
+            // phase A: state machines consume the previous round's results and post their next request
+            pool->parallel_for(nchunks, [&](size_t ci) {
+                ChunkSum cs;
+                const size_t lo = ci * csize, hi = std::min(nlive, lo + csize);
+                for (size_t i = lo; i < hi; i++) {
+                    LsTask *t = live[i];
+                    const bool fr = t->fresh; t->fresh = false;
+                    if (!t->advance(fr ? nullptr : dbase + t->dist_off, fr ? nullptr : pbase + t->pair_out_off)) continue;
+                    alive[i] = 1; cs.alive++;
+                    if (!t->dist_ids.empty()) { cs.dgroups++; cs.dids += t->dist_ids.size(); }
                     for (const PairGroup &pg : t->pgroups) {
-                        c.h_pg_off[s] = (uint32_t)ido; c.h_pg_na[s] = pg.na; c.h_pg_nb[s] = pg.nb; c.h_pg_out_off[s] = oo;
-                        ido += (size_t)pg.na + pg.nb;
-                        oo += pg.nb ? (size_t)pg.na * pg.nb : (size_t)pg.na * (pg.na - 1) / 2;
-                        s++;
+                        cs.pgroups++; cs.pids += (size_t)pg.na + pg.nb;
+                        cs.pout += pg.nb ? (size_t)pg.na * pg.nb : (size_t)pg.na * (pg.na - 1) / 2;
+                    }
+                }
+                sums[ci] = cs;
+            });
+            double t1 = now(); prof[0] += t1 - t0;
+            base.assign(nchunks + 1, ChunkSum());
+            for (size_t c = 0; c < nchunks; c++) {
+                base[c + 1].alive = base[c].alive + sums[c].alive; base[c + 1].dgroups = base[c].dgroups + sums[c].dgroups;
+                base[c + 1].dids = base[c].dids + sums[c].dids; base[c + 1].pgroups = base[c].pgroups + sums[c].pgroups;
+                base[c + 1].pids = base[c].pids + sums[c].pids; base[c + 1].pout = base[c].pout + sums[c].pout;
+            }
+            const ChunkSum &tot = base[nchunks];
+            // admit fresh tasks into the freed slots (they post their first request next round)
+            size_t n_new = std::min(tasks.size() - admitted, window - tot.alive);
+            live2.resize(tot.alive + n_new);
+            if (tot.alive == 0 && n_new == 0) break;
+            HxRound rd; rd.n_dgroups = (uint32_t)tot.dgroups; rd.n_dids = (uint32_t)tot.dids; rd.n_pgroups = (uint32_t)tot.pgroups;
+            rd.n_pids = (uint32_t)tot.pids; rd.n_pout = tot.pout;
+            if ((rc = e->layout_round(rd))) { rc = fail(rc, e->err); break; }
+            double t2 = now(); prof[1] += t2 - t1;
+            HxChannel &c = e->ch;
+            // phase B: compaction + request fill, each chunk at its prefix offsets
+            pool->parallel_for(nchunks, [&](size_t ci) {
+                ChunkSum o = base[ci];
+                const size_t lo = ci * csize, hi = std::min(nlive, lo + csize);
+                for (size_t i = lo; i < hi; i++) {
+                    if (!alive[i]) continue;
+                    LsTask *t = live[i];
+                    live2[o.alive++] = t;
+                    t->dist_off = o.dids; t->pair_out_off = o.pout;
+                    if (!t->dist_ids.empty()) {
+                        c.h_grp_q[o.dgroups] = t->q_sel; c.h_grp_off[o.dgroups] = (uint32_t)o.dids; o.dgroups++;
+                        memcpy(c.h_ids + o.dids, t->dist_ids.data(), t->dist_ids.size() * sizeof(uint32_t));
+                        o.dids += t->dist_ids.size();
+                    }
+                    if (!t->pgroups.empty()) {
+                        memcpy(c.h_pids + o.pids, t->pair_ids.data(), t->pair_ids.size() * sizeof(uint32_t));
+                        for (const PairGroup &pg : t->pgroups) {
+                            c.h_pg_off[o.pgroups] = (uint32_t)o.pids; c.h_pg_na[o.pgroups] = pg.na; c.h_pg_nb[o.pgroups] = pg.nb;
+                            c.h_pg_out_off[o.pgroups] = o.pout; o.pgroups++;
+                            o.pids += (size_t)pg.na + pg.nb;
+                            o.pout += pg.nb ? (size_t)pg.na * pg.nb : (size_t)pg.na * (pg.na - 1) / 2;
+                        }
                     }
                 }
             });
-            c.h_grp_off[n_dgroups] = (uint32_t)n_dids;
-            c.h_pg_off[n_pgroups] = (uint32_t)n_pids;
-            if ((rc = e->run_dist((uint32_t)n_dgroups, (uint32_t)n_dids))) return fail(rc, e->err);
-            if ((rc = e->run_pair((uint32_t)n_pgroups, (uint32_t)n_pids, n_pout))) return fail(rc, e->err);
+            c.h_grp_off[tot.dgroups] = (uint32_t)tot.dids;
+            c.h_pg_off[tot.pgroups] = (uint32_t)tot.pids;
+            for (size_t k = 0; k < n_new; k++) { LsTask *t = tasks[admitted++]; t->fresh = true; live2[tot.alive + k] = t; }
+            live.swap(live2);
+            double t3 = now(); prof[2] += t3 - t2;
+            if ((rc = e->run_round())) { rc = fail(rc, e->err); break; }
+            prof[3] += now() - t3; prof[5] += 1.0;
         }
-        return HX_OK;
+        pool->set_hot(false);
+        return rc;
     }
 };
 
@@ -668,11 +714,12 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
     if (!ix) return HX_E_ARG;
     BatchState &bs = ix->bs; Graph &g = ix->g;
     if (!bs.open || lo > hi || hi > bs.b) return ix->fail(HX_E_STATE, "no open batch / bad member range");
-    std::vector<std::unique_ptr<InsertTask>> its(hi - lo);
+    std::vector<std::unique_ptr<InsertTask>> &its = ix->insert_pool;
+    while (its.size() < hi - lo) its.emplace_back(new InsertTask());
     std::vector<LsTask *> tasks(hi - lo);
     for (uint32_t i = lo; i < hi; i++) {
-        its[i - lo].reset(new InsertTask());
         InsertTask &t = *its[i - lo];
+        t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
         t.g = &g; t.id = bs.base + i; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
         tasks[i - lo] = &t;
     }
@@ -779,16 +826,18 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         bs.grp.push_back({s, t});
         s = t;
     }
-    std::vector<std::unique_ptr<BacklinkTask>> bts; std::vector<LsTask *> btasks;
+    std::vector<std::unique_ptr<BacklinkTask>> &bts = ix->backlink_pool; std::vector<LsTask *> btasks;
+    size_t nbt = 0;
     for (const auto &gr : bs.grp) {
         if (ops[gr.first].target % world != rank) continue;
-        bts.emplace_back(new BacklinkTask());
-        BacklinkTask &bt = *bts.back();
+        if (nbt == bts.size()) bts.emplace_back(new BacklinkTask());
+        BacklinkTask &bt = *bts[nbt++];
+        bt.k = 0; bt.selecting = false; bt.n_dist = bt.n_pair = 0; bt.clear_req();
         bt.g = &g; bt.target = ops[gr.first].target; bt.layer = ops[gr.first].layer; bt.ops.assign(ops.begin() + gr.first, ops.begin() + gr.second);
         btasks.push_back(&bt);
     }
     if ((rc = ix->run_lockstep(btasks))) return rc;
-    for (auto &bt : bts) ix->counters[3] += bt->n_pair;
+    for (size_t i = 0; i < nbt; i++) ix->counters[3] += bts[i]->n_pair;
     bs.linked = true;
     return HX_OK;
 }
@@ -918,6 +967,14 @@ int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t coun
     return HX_OK;
 }
 
+int hx_index_profile(const hx_index *ix, double seconds_out[8], int reset)
+{
+    if (!ix || !seconds_out) return HX_E_ARG;
+    memcpy(seconds_out, ix->prof, sizeof ix->prof);
+    if (reset) memset(const_cast<hx_index *>(ix)->prof, 0, sizeof ix->prof);
+    return HX_OK;
+}
+
 int hx_index_counters(const hx_index *ix, uint64_t counters_out[8])
 {
     if (!ix || !counters_out) return HX_E_ARG;
@@ -933,10 +990,12 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
     if (!tids_out || !counts_out) return ix->fail(HX_E_ARG, "NULL argument");
     if (ef_search < 1 || ef_search > 1000) return ix->fail(HX_E_ARG, "hnsw.ef_search must be between 1 and 1000");   // options.rs:156-166
     if (nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
-    std::vector<std::unique_ptr<QueryTask>> qs(nq); std::vector<LsTask *> tasks(nq);
+    std::vector<std::unique_ptr<QueryTask>> &qs = ix->query_pool; std::vector<LsTask *> tasks(nq);
+    while (qs.size() < nq) qs.emplace_back(new QueryTask());
     for (uint32_t q = 0; q < nq; q++) {
-        qs[q].reset(new QueryTask());
         QueryTask &t = *qs[q];
+        t.st = QueryTask::Q_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req(); t.tuples = 0; t.previous_distance = -HUGE_VAL;
+        t.out_tid.clear(); t.out_d.clear(); t.out_elem.clear(); t.discarded.clear(); t.results.clear();
         t.g = &ix->g; t.slot = q; t.ef_search = ef_search; t.mode = mode; t.max_scan_tuples = max_scan_tuples; t.limit = limit;
         t.filter = filter; t.n_filter = n_filter;
         tasks[q] = &t;

@@ -8,25 +8,29 @@
 
 #include "../../include/hnswrx.h"
 
-// One request channel = pinned host staging + device mirrors for the id/offset/result arrays of a launch.
-// The lock-step driver writes its requests straight into the pinned arrays (no extra copy).
+// One request channel = ONE pinned host buffer + ONE device mirror for everything a lock-step round sends
+// (group query selectors, offsets, row ids, pair-group descriptors, workgroup table) and ONE pair of buffers for
+// what it gets back (K1 distances, K2 pair distances): a round costs one H2D copy, <= 2 kernels, one D2H copy,
+// one stream sync.  The pointers below are sub-arrays of those packed buffers, valid after layout_round().
+// The lock-step driver writes its requests straight into the h_* arrays (no extra copy).
+struct HxRound { uint32_t n_dgroups = 0, n_dids = 0, n_pgroups = 0, n_pids = 0; uint64_t n_pout = 0; };
+
 struct HxChannel {
+    uint8_t *h_req = nullptr, *d_req = nullptr; size_t cap_req = 0, req_bytes = 0;
+    uint8_t *h_res = nullptr, *d_res = nullptr; size_t cap_res = 0, res_bytes = 0;
+    HxRound round; uint32_t max_wgs = 0;
     // distance groups (hx_distances_batch shape)
     uint32_t *h_grp_q = nullptr, *h_grp_off = nullptr, *h_ids = nullptr;
-    float *h_out = nullptr;
     uint32_t *d_grp_q = nullptr, *d_grp_off = nullptr, *d_ids = nullptr;
-    float *d_out = nullptr;
-    size_t cap_groups = 0, cap_ids = 0;
-    // pair groups (hx_pairwise_many shape)
-    uint32_t *h_pg_off = nullptr, *h_pids = nullptr, *h_wg_tab = nullptr;   // wg_tab: {group, first pair} per workgroup
+    float *h_out = nullptr, *d_out = nullptr;
+    // pair groups (hx_pairwise_many shape); wg_tab: {group, first pair} per workgroup
+    uint32_t *h_pg_off = nullptr, *h_pids = nullptr, *h_wg_tab = nullptr;
     uint16_t *h_pg_na = nullptr, *h_pg_nb = nullptr;
     uint64_t *h_pg_out_off = nullptr;
-    float *h_pout = nullptr;
     uint32_t *d_pg_off = nullptr, *d_pids = nullptr, *d_wg_tab = nullptr;
     uint16_t *d_pg_na = nullptr, *d_pg_nb = nullptr;
     uint64_t *d_pg_out_off = nullptr;
-    float *d_pout = nullptr;
-    size_t cap_pgroups = 0, cap_pids = 0, cap_pout = 0, cap_wg = 0;
+    float *h_pout = nullptr, *d_pout = nullptr;
 };
 
 struct HxKernelStat { uint64_t launches = 0, units = 0; double ms = 0.0; };
@@ -37,17 +41,16 @@ struct hx_engine {
     uint8_t *d_rows = nullptr;
     uint8_t *d_queries = nullptr; uint32_t cap_queries = 0, n_queries = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timing = false; float last_ms = 0.f;
     HxKernelStat stat_dist, stat_pair;
     HxChannel ch;
     std::string err;
 
-    // internal (driver-facing) entry points; arrays live in ch.h_* and results land in ch.h_out / ch.h_pout
-    int ensure_dist_capacity(size_t groups, size_t ids);
-    int ensure_pair_capacity(size_t groups, size_t ids, size_t outs);
-    int run_dist(uint32_t n_groups, uint32_t n_ids);                 // blocking: H2D, kernel, D2H, sync
-    int run_pair(uint32_t n_groups, uint32_t n_ids, uint64_t n_out); // blocking
+    // internal (driver-facing) entry points: size the packed buffers for a round and point ch.h_*/d_* into them;
+    // then (after the caller filled the h_* request arrays) copy, launch K1 and/or K2, copy back, sync.
+    int layout_round(const HxRound &r);
+    int run_round();
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 
