@@ -199,8 +199,15 @@ int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t coun
  * [1] search_layer expansions, [2] select_neighbors in find_element_neighbors, [3] back-link pruning, [4] scan */
 int hx_index_counters(const hx_index *ix, uint64_t counters_out[8]);
 
+/* Traversal placement.  enabled (default): find_element_neighbors and non-iterative scans run in the device-resident
+ * fused kernel (one wavefront per search, heaps in LDS); a task that overflows its LDS budget is re-run by the
+ * lock-step host driver.  disabled: everything runs in the lock-step driver.  Both produce identical results.
+ * fused_stats: tasks given to the fused kernel and how many of them had to be re-run. */
+int hx_index_set_fused(hx_index *ix, int enabled);
+int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone);
+
 /* host-side wall time of the lock-step driver since the last reset, seconds: [0] task state machines,
- * [1] request compaction, [2] request fill, [3] K1 copies+launch+wait, [4] K2 copies+launch+wait, [5] rounds */
+ * [1] request compaction, [2] request fill, [3] round copies+launches+wait, [4] unused, [5] rounds, [6] fused kernel calls */
 int hx_index_profile(const hx_index *ix, double seconds_out[8], int reset);
 
 /* get_scan_items + amgettuple (scan.rs:458-530, 709-876), iterative_scan = off, for nq queries in

@@ -83,6 +83,8 @@ def lib():
         "hx_index_set_neighbors": (i32, [vp, u32, i32, u32, vp, vp]),
         "hx_index_counters": (i32, [vp, vp]),
         "hx_index_profile": (i32, [vp, vp, i32]),
+        "hx_index_set_fused": (i32, [vp, i32]),
+        "hx_index_fused_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
         "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
     }
@@ -356,7 +358,15 @@ class Index:
     def profile(self, reset=False):
         p = np.zeros(8, np.float64)
         self._ck(lib().hx_index_profile(self.h, _p(p), int(reset)))
-        return {"advance_s": p[0], "compact_s": p[1], "fill_s": p[2], "k1_s": p[3], "k2_s": p[4], "rounds": int(p[5])}
+        return {"advance_s": p[0], "compact_s": p[1], "fill_s": p[2], "round_s": p[3], "rounds": int(p[5]), "fused_s": p[6]}
+
+    def set_fused(self, on):
+        self._ck(lib().hx_index_set_fused(self.h, int(on)))
+
+    def fused_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(lib().hx_index_fused_stats(self.h, C.byref(a), C.byref(b)))
+        return {"tasks": a.value, "redone": b.value}
 
     def search(self, nq, ef_search, k):
         tids = np.full((nq, k), -1, np.int64)

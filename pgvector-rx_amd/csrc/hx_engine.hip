@@ -516,6 +516,8 @@ int hx_engine::run_round()
     return HX_OK;
 }
 
+#include "hx_fused.inc.h"
+
 // =================================================================================================
 // C ABI: engine
 // =================================================================================================
@@ -574,8 +576,9 @@ int hx_destroy(hx_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     HxChannel &c = e->ch;
-    void *hp[] = {c.h_req, c.h_res};
-    void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries};
+    HxMirror &mr = e->mirror;
+    void *hp[] = {c.h_req, c.h_res, mr.h_stage, mr.h_io};
+    void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries, mr.d_l0_ids, mr.d_l0_cnt, mr.d_level, mr.d_up_block, mr.d_up_ids, mr.d_up_cnt, mr.d_vis, mr.d_stage, mr.d_io};
     for (void *p : hp) if (p) (void)hipHostFree(p);
     for (void *p : dp) if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -844,7 +847,7 @@ int hx_last_kernel_ms(hx_engine *e, float *ms) { if (!e || !ms) return HX_E_ARG;
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset)
 {
     if (!e) return HX_E_ARG;
-    HxKernelStat &s = kind == 0 ? e->stat_dist : e->stat_pair;
+    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : e->stat_fused;
     if (launches) *launches = s.launches;
     if (units) *units = s.units;
     if (ms) *ms = s.ms;

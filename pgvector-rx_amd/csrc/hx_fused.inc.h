@@ -1,0 +1,546 @@
+// hx_fused.inc.h -- included by hx_engine.hip.  Device-resident HNSW traversal: one wavefront per search.
+//
+// The lock-step host driver (hx_index.cpp) pays one host round trip per candidate expansion.  This file moves the
+// whole of search_layer (graph/mod.rs:161-255 / scan.rs:302-448), the greedy descent and per-layer loop of
+// find_element_neighbors (graph/mod.rs:355-427) / get_scan_items (scan.rs:458-530) and select_neighbors
+// (graph/mod.rs:269-339) into ONE persistent kernel:
+//   * a 64-thread workgroup (one wavefront) owns one insert or query from start to finish; workgroups pull tasks
+//     from an atomic counter until none are left (every wave reaches the exit: the counter only grows);
+//   * the candidate heap C, the result heap W, the entry-point / sorted-candidate array and the select lists live
+//     in LDS; the heaps use the same Rust-std sift order as the host driver and the oracle, executed by lane 0;
+//   * the query's 16-byte fragments stay in registers; an expansion reads the candidate's neighbour ids (coalesced),
+//     test-and-sets a per-workgroup visited bitmap with L2 atomics, and evaluates the unvisited rows with the SAME
+//     canonical summation order as K1/K2 (lane l owns bytes chunk*1024+16*l, xor butterfly), 4 rows in flight;
+//   * the graph is read from a device mirror (ids only) that the host refreshes after each batch.
+// Results (neighbour lists with distances / top-k) are therefore bit-identical to the lock-step path; the
+// tests compare the two paths and the oracle.  A task whose candidate heap would overflow its LDS budget reports
+// FS_OVERFLOW and is re-run by the lock-step path (still on the GPU kernels: there is no CPU fallback).
+
+#define FUSED_MAXCH 8          /* 1 KiB chunks per row: pitch <= 8192 B covers vector(2000), halfvec(4000), bit(64000) */
+#define FUSED_RB 4             /* rows in flight per wave */
+#define FUSED_MAXL 8           /* layers 0..7 handled on the device (P(level >= 8) = 16^-8 at m=16) */
+enum { FS_OK = 0, FS_OVERFLOW = 1, FS_HOST = 2 };
+
+struct FusedParams {
+    const uint8_t *rows, *queries; uint32_t pitch, nch; uint64_t n_rows;
+    const uint32_t *l0_ids; const uint16_t *l0_cnt; const int32_t *level;
+    const uint32_t *up_block, *up_ids; const uint16_t *up_cnt;
+    uint32_t m, entry; int32_t entry_level;
+    uint32_t ntasks; const uint32_t *t_qsel; const int32_t *t_level;
+    uint32_t ef, k, ccap;
+    uint32_t *vis; uint64_t vis_words;            // per-workgroup visited bitmap, vis_words 32-bit words each
+    uint32_t *next_task;
+    uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
+    unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances
+};
+
+struct FHeapItem { float d; uint32_t id; };
+__device__ __forceinline__ uint2 fh_pack(float d, uint32_t id) { return make_uint2(__builtin_bit_cast(unsigned int, d), id); }
+__device__ __forceinline__ float fh_d(const uint2 &v) { return __builtin_bit_cast(float, v.x); }
+
+// Rust std BinaryHeap on an LDS array; NEAREST: smallest distance on top.  Called by ONE lane.
+template <bool NEAREST> struct FHeap {
+    static __device__ __forceinline__ bool le(float a, float b) { return NEAREST ? !(b > a) : !(a > b); }
+    static __device__ void sift_up(uint2 *h, uint32_t start, uint32_t pos)
+    {
+        const uint2 e = h[pos]; const float ed = fh_d(e);
+        while (pos > start) {
+            const uint32_t parent = (pos - 1) >> 1;
+            const uint2 pv = h[parent];
+            if (le(ed, fh_d(pv))) break;
+            h[pos] = pv; pos = parent;
+        }
+        h[pos] = e;
+    }
+    static __device__ void push(uint2 *h, uint32_t &len, uint2 c) { h[len] = c; len++; sift_up(h, 0, len - 1); }
+    static __device__ uint2 pop(uint2 *h, uint32_t &len)      // len > 0
+    {
+        uint2 item = h[len - 1]; len--;
+        if (len > 0) {
+            const uint2 top = h[0]; h[0] = item; item = top;
+            // sift_down_to_bottom(0)
+            const uint32_t end = len; uint32_t pos = 0;
+            const uint2 e = h[0];
+            uint32_t child = 1;
+            while (end >= 2 && child <= end - 2) {
+                const uint2 a = h[child], b = h[child + 1];
+                const bool right = le(fh_d(a), fh_d(b));
+                h[pos] = right ? b : a; pos = child + (right ? 1u : 0u); child = 2 * pos + 1;
+            }
+            if (child == end - 1) { h[pos] = h[child]; pos = child; }
+            h[pos] = e;
+            sift_up(h, 0, pos);
+        }
+        return item;
+    }
+};
+
+struct FusedCtx {
+    uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL;
+    uint32_t *vis; uint32_t lane; uint32_t status;
+    unsigned long long nd0, nd1;
+};
+
+// 16-byte fragments of one vector (row or query slot) into registers; lanes past the pitch hold zeros
+__device__ __forceinline__ void f_load_frags(const FusedParams &p, const uint8_t *src, uint32_t lane, u4 (&f)[FUSED_MAXCH])
+{
+#pragma unroll
+    for (int c = 0; c < FUSED_MAXCH; c++) {
+        const uint32_t off = c * 1024u + lane * 16u;
+        u4 v = {0u, 0u, 0u, 0u};
+        if ((uint32_t)c < p.nch && off < p.pitch) v = *(const u4 *)(src + off);
+        f[c] = v;
+    }
+}
+
+// distances from the fragment set f to rows ids[0..n) (LDS); lane j (< 64) returns d(f, ids[j]); n <= 64
+template <class OP>
+__device__ __forceinline__ float f_dist_batch(const FusedParams &p, const u4 (&f)[FUSED_MAXCH], const uint32_t *ids, uint32_t n, uint32_t lane)
+{
+    float mine = 0.0f;
+    for (uint32_t j0 = 0; j0 < n; j0 += FUSED_RB) {
+        u4 rv[FUSED_RB][FUSED_MAXCH];
+#pragma unroll
+        for (int r = 0; r < FUSED_RB; r++) {
+            const uint32_t j = j0 + r < n ? j0 + r : j0;
+            const uint8_t *rp = p.rows + (size_t)ids[j] * p.pitch;
+#pragma unroll
+            for (int c = 0; c < FUSED_MAXCH; c++) {
+                const uint32_t off = c * 1024u + lane * 16u;
+                u4 v = {0u, 0u, 0u, 0u};
+                if ((uint32_t)c < p.nch && off < p.pitch) v = *(const u4 *)(rp + off);
+                rv[r][c] = v;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FUSED_RB; r++) {
+            typename OP::acc_t acc; OP::init(acc);
+#pragma unroll
+            for (int c = 0; c < FUSED_MAXCH; c++)
+                if ((uint32_t)c < p.nch) OP::add(acc, f[c], rv[r][c]);
+            const float d = OP::template finish<64>(acc);
+            if (j0 + r < n && lane == j0 + r) mine = d;
+        }
+    }
+    return mine;
+}
+
+// Algorithm 2 with entry points EP[0..n_ep); leaves the result set in the W heap (cx.CTL[1] = |W|).
+// scan == false: search_layer (graph/mod.rs:161-255); scan == true: search_layer_disk without `discarded` (scan.rs:302-448).
+template <class OP>
+__device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, const u4 (&qf)[FUSED_MAXCH], uint32_t n_ep, uint32_t ef, int layer, bool scan)
+{
+    const uint32_t lane = cx.lane;
+    // fresh visited set
+    for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{0u, 0u, 0u, 0u};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t i = lane; i < n_ep; i += 64) { const uint32_t e = cx.EP[i].y; atomicOr(&cx.vis[e >> 5], 1u << (e & 31u)); }
+    if (lane == 0) {
+        uint32_t clen = 0, wlen = 0;
+        for (uint32_t i = 0; i < n_ep; i++) {
+            if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
+            FHeap<true>::push(cx.C, clen, cx.EP[i]); FHeap<false>::push(cx.W, wlen, cx.EP[i]);
+        }
+        cx.CTL[0] = clen; cx.CTL[1] = wlen; cx.CTL[2] = wlen;     // C len, W len, result_len
+    }
+    __syncthreads();
+    cx.status = __shfl(cx.status, 0, 64);
+    for (;;) {
+        if (cx.status != FS_OK) break;
+        // pop the nearest candidate (lane 0), decide whether to stop
+        if (lane == 0) {
+            uint32_t clen = cx.CTL[0]; const uint32_t wl = cx.CTL[1];
+            uint32_t go = 0, cid = 0;
+            if (clen > 0) {
+                const uint2 c = FHeap<true>::pop(cx.C, clen);
+                const float cd = fh_d(c);
+                bool stop;
+                if (!scan) { const float f = wl ? fh_d(cx.W[0]) : 3.402823466e+38f; stop = cd > f; }                     // mod.rs:188-193
+                else { const double f = wl ? (double)fh_d(cx.W[0]) : 1.7976931348623157e+308; stop = (double)cd > f; }    // scan.rs:339-346
+                if (!stop) { go = 1; cid = c.y; }
+            }
+            cx.CTL[0] = clen; cx.CTL[3] = go; cx.CTL[4] = cid;
+        }
+        __syncthreads();
+        const uint32_t go = cx.CTL[3], cid = cx.CTL[4];
+        __syncthreads();
+        if (!go) break;
+        if (p.level[cid] < layer) continue;                                          // mod.rs:198-200
+        const uint32_t *nb; uint32_t n;
+        if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; n = p.l0_cnt[cid]; }
+        else { const uint32_t blk = p.up_block[cid] + (uint32_t)(layer - 1); nb = p.up_ids + (size_t)blk * p.m; n = p.up_cnt[blk]; }
+        for (uint32_t n0 = 0; n0 < n; n0 += 64) {                                    // lists longer than a wave (m > 32) go in order
+            const uint32_t idx = n0 + lane;
+            uint32_t e = 0; bool unvis = false;
+            if (idx < n) {
+                e = nb[idx];
+                const uint32_t bit = 1u << (e & 31u);
+                const uint32_t old = atomicOr(&cx.vis[e >> 5], bit);                 // visited.contains / insert, mod.rs:206-209
+                unvis = (old & bit) == 0;
+                if (unvis && layer > 0 && p.level[e] < layer) unvis = false;         // mod.rs:213-216
+            }
+            const unsigned long long mask = __ballot(unvis);
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            if (cnt == 0) continue;
+            if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
+            __syncthreads();
+            const float mine = f_dist_batch<OP>(p, qf, cx.IDS, cnt, lane);
+            if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
+            cx.nd0 += cnt;
+            __syncthreads();
+            if (lane == 0) {                                                         // replay in list order, mod.rs:226-243 / scan.rs:372-429
+                uint32_t clen = cx.CTL[0], wl = cx.CTL[1], rlen = cx.CTL[2];
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint2 it = cx.RES[j]; const float d = fh_d(it);
+                    const bool always_add = rlen < ef;
+                    bool add;
+                    if (!scan) { const float f = wl ? fh_d(cx.W[0]) : 3.402823466e+38f; add = d < f || always_add; }
+                    else { const double f = wl ? (double)fh_d(cx.W[0]) : 1.7976931348623157e+308; add = !(!always_add && (double)d >= f); }
+                    if (!add) continue;
+                    if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
+                    FHeap<true>::push(cx.C, clen, it); FHeap<false>::push(cx.W, wl, it); rlen++;
+                    if (rlen > ef) { (void)FHeap<false>::pop(cx.W, wl); rlen--; }
+                }
+                cx.CTL[0] = clen; cx.CTL[1] = wl; cx.CTL[2] = rlen;
+            }
+            __syncthreads();
+            cx.status = __shfl(cx.status, 0, 64);
+            if (cx.status != FS_OK) break;
+        }
+    }
+    __syncthreads();
+}
+
+// stable sort of the W heap's internal array into EP: ascending (build, mod.rs:248-254) or descending (scan.rs:441-446);
+// rank sort: ties keep their order in W's array, exactly what a stable sort of that array does
+__device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
+{
+    for (uint32_t i = cx.lane; i < n; i += 64) {
+        const uint2 me = cx.W[i]; const float d = fh_d(me);
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const float dj = fh_d(cx.W[j]);
+            rank += (desc ? dj > d : dj < d) || (dj == d && j < i);
+        }
+        cx.EP[rank] = me;
+    }
+    __syncthreads();
+}
+
+template <class OP, int MODE>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors)
+__global__ void __launch_bounds__(64)
+k_fused(const FusedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    FusedCtx cx;
+    const uint32_t lm0 = 2u * p.m;
+    cx.C = (uint2 *)lds;
+    cx.W = cx.C + p.ccap;
+    cx.EP = cx.W + (p.ef + 2);
+    cx.RES = cx.EP + (p.ef + 2);
+    cx.RL = cx.RES + 64;
+    cx.DL = cx.RL + lm0;
+    cx.IDS = (uint32_t *)(cx.DL + (p.ef + 2));
+    cx.CTL = cx.IDS + 64;
+    cx.lane = threadIdx.x;
+    cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
+    cx.nd0 = cx.nd1 = 0;
+    const uint32_t lane = cx.lane;
+
+    for (;;) {
+        if (lane == 0) cx.CTL[5] = atomicAdd(p.next_task, 1u);
+        __syncthreads();
+        const uint32_t t = cx.CTL[5];
+        __syncthreads();
+        if (t >= p.ntasks) break;
+        cx.status = FS_OK;
+        const uint32_t qsel = p.t_qsel[t];
+        const uint8_t *qsrc = (qsel & HX_QUERY_SLOT) ? p.queries + (size_t)(qsel & 0x7fffffffu) * p.pitch : p.rows + (size_t)qsel * p.pitch;
+        u4 qf[FUSED_MAXCH];
+        f_load_frags(p, qsrc, lane, qf);
+        const int new_level = MODE == 1 ? p.t_level[t] : -1;
+        if (MODE == 1 && new_level >= FUSED_MAXL) { if (lane == 0) p.status[t] = FS_HOST; continue; }
+
+        // d(q, entry point): mod.rs:371-377 / scan.rs:475
+        if (lane == 0) cx.IDS[0] = p.entry;
+        __syncthreads();
+        const float d0 = f_dist_batch<OP>(p, qf, cx.IDS, 1, lane);
+        cx.nd0 += 1;
+        if (lane == 0) cx.EP[0] = fh_pack(d0, p.entry);
+        __syncthreads();
+        uint32_t n_ep = 1;
+
+        // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
+        const int stop_above = MODE == 1 ? new_level : 0;
+        for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
+            f_search_layer<OP>(p, cx, qf, n_ep, 1u, lc, MODE == 0);
+            const uint32_t wl = cx.CTL[1];
+            if (wl > 0) {
+                f_sort_results(cx, wl, MODE == 0);
+                if (MODE == 0) { const uint2 best = cx.EP[wl - 1]; __syncthreads(); if (lane == 0) cx.EP[0] = best; __syncthreads(); }
+                n_ep = 1;                         // MODE 1: ep = vec![w[0]]; EP[0] already is the nearest
+            } else if (MODE == 0) { n_ep = 0; break; }
+        }
+
+        if (MODE == 0) {
+            uint32_t cnt = 0;
+            if (cx.status == FS_OK && n_ep > 0) {
+                f_search_layer<OP>(p, cx, qf, n_ep, p.ef, 0, true);                  // scan.rs:515-528
+                const uint32_t wl = cx.CTL[1];
+                f_sort_results(cx, wl, true);                                        // nearest LAST
+                cnt = wl < p.k ? wl : p.k;
+                for (uint32_t i = lane; i < cnt; i += 64) {                          // amgettuple pops from the back
+                    const uint2 v = cx.EP[wl - 1 - i];
+                    p.out_ids[(size_t)t * p.k + i] = v.y; p.out_d[(size_t)t * p.k + i] = fh_d(v);
+                }
+            }
+            if (lane == 0) { p.out_cnt[t] = cnt; p.status[t] = cx.status; }
+        } else {
+            const int start = new_level < p.entry_level ? new_level : p.entry_level;
+            const size_t obase = (size_t)t * FUSED_MAXL;
+            for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
+            for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
+                const uint32_t lm = lc == 0 ? lm0 : p.m;
+                f_search_layer<OP>(p, cx, qf, n_ep, p.ef, lc, false);                // mod.rs:407-416
+                if (cx.status != FS_OK) break;
+                const uint32_t wl = cx.CTL[1];
+                f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
+                n_ep = wl;
+                // select_neighbors(W, lm): mod.rs:269-308
+                uint32_t r = 0, nd = 0;
+                if (wl <= lm) {
+                    for (uint32_t i = lane; i < wl; i += 64) cx.RL[i] = cx.EP[i];
+                    r = wl;
+                } else {
+                    for (uint32_t i = 0; i < wl; i++) {
+                        if (r >= lm) break;                                          // mod.rs:285-287
+                        const uint2 e = cx.EP[i];
+                        bool closer = true;                                          // check_element_closer, mod.rs:315-339
+                        if (r > 0) {
+                            u4 ef_[FUSED_MAXCH];
+                            f_load_frags(p, p.rows + (size_t)e.y * p.pitch, lane, ef_);
+                            if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
+                            __syncthreads();
+                            const float dj = f_dist_batch<OP>(p, ef_, cx.IDS, r, lane);
+                            cx.nd1 += r;
+                            closer = __ballot(lane < r && dj <= fh_d(e)) == 0ull;    // mod.rs:333-335 (any r rejects)
+                            __syncthreads();
+                        }
+                        if (lane == 0) { if (closer) cx.RL[r] = e; else cx.DL[nd] = e; }
+                        if (closer) r++; else nd++;
+                        __syncthreads();
+                    }
+                    __syncthreads();
+                    if (lane == 0) for (uint32_t j = 0; j < nd && r < lm; j++) cx.RL[r++] = cx.DL[j];   // mod.rs:300-305
+                    r = __shfl(r, 0, 64);
+                }
+                __syncthreads();
+                const size_t lb = ((size_t)t * FUSED_MAXL + (size_t)lc) * lm0;
+                for (uint32_t i = lane; i < r; i += 64) { const uint2 v = cx.RL[i]; p.out_ids[lb + i] = v.y; p.out_d[lb + i] = fh_d(v); }
+                if (lane == 0) p.out_cnt[obase + lc] = r;
+                __syncthreads();
+            }
+            if (lane == 0) p.status[t] = cx.status;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); }
+}
+
+// ---- device graph mirror maintenance ------------------------------------------------------------------------
+__global__ void k_mirror_levels(int32_t *level, uint32_t *up_block, uint32_t first, uint32_t n, const int32_t *lv, const uint32_t *blk)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { level[first + i] = lv[i]; up_block[first + i] = blk[i]; }
+}
+// one 64-thread block per record: {elem, layer, cnt, block} + ids[stride]
+__global__ void k_mirror_lists(uint32_t *l0_ids, uint16_t *l0_cnt, uint32_t *up_ids, uint16_t *up_cnt, uint32_t m,
+                               uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids, uint32_t stride)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= n_rec) return;
+    const uint32_t elem = hdr[4 * r], layer = hdr[4 * r + 1], cnt = hdr[4 * r + 2], blk = hdr[4 * r + 3];
+    const uint32_t *src = ids + (size_t)r * stride;
+    if (layer == 0) {
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) l0_ids[(size_t)elem * 2u * m + k] = src[k];
+        if (threadIdx.x == 0) l0_cnt[elem] = (uint16_t)cnt;
+    } else {
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) up_ids[(size_t)blk * m + k] = src[k];
+        if (threadIdx.x == 0) up_cnt[blk] = (uint16_t)cnt;
+    }
+}
+
+template <class T> static int mirror_grow(hx_engine *e, T *&p, size_t old_n, size_t new_n)
+{
+    T *q = nullptr;
+    HX_HIP(e, hipMalloc((void **)&q, new_n * sizeof(T)));
+    HX_HIP(e, hipMemsetAsync(q, 0, new_n * sizeof(T), e->stream));
+    if (p && old_n) HX_HIP(e, hipMemcpyAsync(q, p, old_n * sizeof(T), hipMemcpyDeviceToDevice, e->stream));
+    HX_HIP(e, hipStreamSynchronize(e->stream));
+    if (p) (void)hipFree(p);
+    p = q;
+    return HX_OK;
+}
+
+int hx_engine::mirror_reserve(uint32_t m, uint64_t n_elems, uint64_t n_blocks)
+{
+    HxMirror &mr = mirror;
+    int rc;
+    if (mr.m == 0) mr.m = m;
+    if (mr.m != m) return fail(HX_E_STATE, "mirror m mismatch");
+    if (n_elems > mr.cap) {
+        const uint64_t nc = std::max<uint64_t>(std::max<uint64_t>(n_elems, capacity), mr.cap * 2);
+        if ((rc = mirror_grow(this, mr.d_l0_ids, mr.cap * 2 * m, nc * 2 * m))) return rc;
+        if ((rc = mirror_grow(this, mr.d_l0_cnt, mr.cap, nc))) return rc;
+        if ((rc = mirror_grow(this, mr.d_level, mr.cap, nc))) return rc;
+        if ((rc = mirror_grow(this, mr.d_up_block, mr.cap, nc))) return rc;
+        mr.cap = nc;
+    }
+    if (n_blocks > mr.cap_blocks) {
+        const uint64_t nb = std::max<uint64_t>(std::max<uint64_t>(n_blocks, capacity / 8 + 1024), mr.cap_blocks * 2);
+        if ((rc = mirror_grow(this, mr.d_up_ids, mr.cap_blocks * m, nb * m))) return rc;
+        if ((rc = mirror_grow(this, mr.d_up_cnt, mr.cap_blocks, nb))) return rc;
+        mr.cap_blocks = nb;
+    }
+    return HX_OK;
+}
+
+// levels/up_block of elements [first, first+n_new) and n_rec list records (hdr: elem, layer, cnt, block; ids: stride 2m)
+int hx_engine::mirror_update(uint32_t first, uint32_t n_new, const int32_t *levels, const uint32_t *blocks,
+                             uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids)
+{
+    HxMirror &mr = mirror;
+    const uint32_t stride = 2 * mr.m;
+    const size_t bytes = (size_t)n_new * 8 + (size_t)n_rec * (16 + (size_t)stride * 4);
+    if (bytes == 0) return HX_OK;
+    if (bytes > mr.cap_stage) {
+        if (mr.h_stage) (void)hipHostFree(mr.h_stage);
+        if (mr.d_stage) (void)hipFree(mr.d_stage);
+        mr.h_stage = mr.d_stage = nullptr; mr.cap_stage = 0;
+        const size_t n = bytes * 2 + 4096;
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_stage, n, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&mr.d_stage, n));
+        mr.cap_stage = n;
+    }
+    uint8_t *h = mr.h_stage; size_t o = 0;
+    const size_t o_lv = o; memcpy(h + o, levels, (size_t)n_new * 4); o += (size_t)n_new * 4;
+    const size_t o_bk = o; memcpy(h + o, blocks, (size_t)n_new * 4); o += (size_t)n_new * 4;
+    const size_t o_hdr = o; memcpy(h + o, hdr, (size_t)n_rec * 16); o += (size_t)n_rec * 16;
+    const size_t o_ids = o; memcpy(h + o, ids, (size_t)n_rec * stride * 4); o += (size_t)n_rec * stride * 4;
+    HX_HIP(this, hipMemcpyAsync(mr.d_stage, h, o, hipMemcpyHostToDevice, stream));
+    if (n_new) hipLaunchKernelGGL(k_mirror_levels, dim3((n_new + 255) / 256), dim3(256), 0, stream, mr.d_level, mr.d_up_block, first, n_new,
+                                  (const int32_t *)(mr.d_stage + o_lv), (const uint32_t *)(mr.d_stage + o_bk));
+    if (n_rec) hipLaunchKernelGGL(k_mirror_lists, dim3(n_rec), dim3(64), 0, stream, mr.d_l0_ids, mr.d_l0_cnt, mr.d_up_ids, mr.d_up_cnt, mr.m, n_rec,
+                                  (const uint32_t *)(mr.d_stage + o_hdr), (const uint32_t *)(mr.d_stage + o_ids), stride);
+    HX_HIP(this, hipGetLastError());
+    HX_HIP(this, hipStreamSynchronize(stream));
+    return HX_OK;
+}
+
+template <class OP, int MODE>
+static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds)
+{
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t s = hipFuncSetAttribute((const void *)k_fused<OP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (s != hipSuccess) return s;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_fused<OP, MODE>), dim3(grid), dim3(64), lds, e->stream, p);
+    return hipGetLastError();
+}
+
+template <class OP>
+static hipError_t launch_fused_mode(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
+{
+    return mode == 0 ? launch_fused<OP, 0>(e, p, grid, lds) : launch_fused<OP, 1>(e, p, grid, lds);
+}
+
+// mode 0: ntasks queries -> out_ids/out_d [ntasks][k], out_cnt[ntasks]; mode 1: ntasks inserts -> out_ids/out_d
+// [ntasks][FUSED_MAXL][2m], out_cnt [ntasks][FUSED_MAXL].  status[ntasks].  All host pointers.
+int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
+                         uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
+                         uint64_t counts[2])
+{
+    HxMirror &mr = mirror;
+    if (ntasks == 0) return HX_OK;
+    if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_ARG, "row too wide for the fused kernel");
+    if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
+    HX_HIP(this, hipSetDevice(device));
+    // LDS: C[ccap] W[ef+2] EP[ef+2] RES[64] RL[2m] DL[ef+2] (8 B each) + IDS[64] + CTL[16] (4 B each)
+    uint32_t ccap = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, ef * 12u));
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 3 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16) * 4; };
+    while (lds_bytes(ccap) > 60 * 1024 && ccap > 512) ccap -= 256;
+    const size_t lds = lds_bytes(ccap);
+    // residency: one wave per workgroup, LDS-limited
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
+    const uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
+    const uint64_t vis_words = (((n_rows + 31) / 32) + 3) & ~3ull;
+    if ((uint64_t)grid * vis_words > mr.cap_vis) {
+        if (mr.d_vis) (void)hipFree(mr.d_vis);
+        mr.d_vis = nullptr; mr.cap_vis = 0;
+        const uint64_t n = (uint64_t)256 * 16 * ((((std::max<uint64_t>(n_rows, capacity) + 31) / 32) + 3) & ~3ull);
+        HX_HIP(this, hipMalloc((void **)&mr.d_vis, n * 4));
+        mr.cap_vis = n;
+    }
+    const size_t out_n = mode == 0 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;
+    const size_t cnt_n = mode == 0 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
+    // device task/in/out buffers (one allocation, reused)
+    const size_t need = al16((size_t)ntasks * 4) * 3 + al16(out_n * 4) * 2 + al16(cnt_n * 4) + 64;
+    if (need > mr.cap_io) {
+        if (mr.d_io) (void)hipFree(mr.d_io);
+        if (mr.h_io) (void)hipHostFree(mr.h_io);
+        mr.d_io = mr.h_io = nullptr; mr.cap_io = 0;
+        const size_t n = need * 2;
+        HX_HIP(this, hipMalloc((void **)&mr.d_io, n));
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_io, n, hipHostMallocDefault));
+        mr.cap_io = n;
+    }
+    size_t o = 0;
+    const size_t o_ctr = o; o += 64;
+    const size_t o_q = o; o += al16((size_t)ntasks * 4);
+    const size_t o_lv = o; o += al16((size_t)ntasks * 4);
+    const size_t in_bytes = o;
+    const size_t o_st = o; o += al16((size_t)ntasks * 4);
+    const size_t o_cnt = o; o += al16(cnt_n * 4);
+    const size_t o_ids = o; o += al16(out_n * 4);
+    const size_t o_d = o; o += al16(out_n * 4);
+    memset(mr.h_io + o_ctr, 0, 64);
+    memcpy(mr.h_io + o_q, q_sel, (size_t)ntasks * 4);
+    if (t_level) memcpy(mr.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(mr.h_io + o_lv, 0, (size_t)ntasks * 4);
+    HX_HIP(this, hipMemcpyAsync(mr.d_io, mr.h_io, in_bytes, hipMemcpyHostToDevice, stream));
+    FusedParams p;
+    p.rows = d_rows; p.queries = d_queries; p.pitch = (uint32_t)pitch; p.nch = (uint32_t)((pitch + 1023) / 1024); p.n_rows = n_rows;
+    p.l0_ids = mr.d_l0_ids; p.l0_cnt = mr.d_l0_cnt; p.level = mr.d_level; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_cnt = mr.d_up_cnt;
+    p.m = mr.m; p.entry = entry; p.entry_level = entry_level;
+    p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(mr.d_io + o_q); p.t_level = (const int32_t *)(mr.d_io + o_lv);
+    p.ef = ef; p.k = k; p.ccap = ccap;
+    p.vis = mr.d_vis; p.vis_words = vis_words;
+    p.next_task = (uint32_t *)(mr.d_io + o_ctr);
+    p.n_dist = (unsigned long long *)(mr.d_io + o_ctr + 16);
+    p.out_ids = (uint32_t *)(mr.d_io + o_ids); p.out_d = (float *)(mr.d_io + o_d); p.out_cnt = (uint32_t *)(mr.d_io + o_cnt);
+    p.status = (uint32_t *)(mr.d_io + o_st);
+    if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
+    hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_fused_mode<OpF32<K>>(this, p, grid, lds, mode)
+#define F16C(K) ls = launch_fused_mode<OpF16<K>>(this, p, grid, lds, mode)
+    HX_DISPATCH(this, F32C, F16C, ls = launch_fused_mode<OpHamming>(this, p, grid, lds, mode), ls = launch_fused_mode<OpJaccard>(this, p, grid, lds, mode));
+#undef F32C
+#undef F16C
+    HX_HIP(this, ls);
+    if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, o - o_st, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    memcpy(status, mr.h_io + o_st, (size_t)ntasks * 4);
+    memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
+    memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
+    memcpy(out_d, mr.h_io + o_d, out_n * 4);
+    unsigned long long nd[2]; memcpy(nd, mr.h_io + o_ctr + 16, 16);
+    if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }
+    if (timing) {
+        float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev0, ev1));
+        last_ms = ms; stat_fused.launches++; stat_fused.units += nd[0] + nd[1]; stat_fused.ms += ms;
+    }
+    return HX_OK;
+}

@@ -557,9 +557,43 @@ struct hx_index {
     std::vector<std::unique_ptr<InsertTask>> insert_pool;      // task objects are reused across batches (their heaps,
     std::vector<std::unique_ptr<BacklinkTask>> backlink_pool;  // visited tables and request vectors keep their capacity)
     std::vector<std::unique_ptr<QueryTask>> query_pool;
+    bool fused = true;                                         // device-resident traversal (hx_fused.inc.h) for searches
+    std::vector<std::pair<uint32_t, int>> dirty;               // (element, layer) lists the device mirror has not seen yet
+    uint32_t mirror_elems = 0;
+    uint64_t fused_tasks = 0, fused_redo = 0;
     double prof[8] = {0};   // seconds: [0] advance, [1] compact, [2] fill, [3] dist launch+wait, [4] pair launch+wait, [5] rounds
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
+
+    bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192; }
+    void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
+    // brings the device copy of the graph up to date: levels of new elements + every list written since the last sync
+    int sync_mirror()
+    {
+        const uint32_t m = (uint32_t)g.m;
+        int rc = e->mirror_reserve(m, g.size(), g.up.size() / m + 1);
+        if (rc) return fail(rc, e->err);
+        std::sort(dirty.begin(), dirty.end());
+        dirty.erase(std::unique(dirty.begin(), dirty.end()), dirty.end());
+        const uint32_t n_new = g.size() - mirror_elems, n_rec = (uint32_t)dirty.size();
+        if (n_new == 0 && n_rec == 0) return HX_OK;
+        std::vector<int32_t> lv(n_new); std::vector<uint32_t> blk(n_new);
+        for (uint32_t i = 0; i < n_new; i++) { lv[i] = g.level[mirror_elems + i]; blk[i] = (uint32_t)(g.up_off[mirror_elems + i] / m); }
+        std::vector<uint32_t> hdr((size_t)n_rec * 4), ids((size_t)n_rec * 2 * m, 0u);
+        pool->parallel_for((n_rec + 1023) / 1024, [&](size_t ci) {
+            for (size_t r = ci * 1024; r < std::min<size_t>(n_rec, ci * 1024 + 1024); r++) {
+                const uint32_t el = dirty[r].first; const int layer = dirty[r].second;
+                const bool live = g.level[el] >= layer;
+                const uint16_t c = live ? g.cnt(el, layer) : 0; const Cand *l = live ? g.list(el, layer) : nullptr;
+                hdr[4 * r] = el; hdr[4 * r + 1] = (uint32_t)layer; hdr[4 * r + 2] = c;
+                hdr[4 * r + 3] = layer > 0 ? (uint32_t)(g.up_off[el] / m) + (uint32_t)(layer - 1) : 0u;
+                for (uint16_t k = 0; k < c; k++) ids[r * 2 * m + k] = l[k].id;
+            }
+        });
+        if ((rc = e->mirror_update(mirror_elems, n_new, lv.data(), blk.data(), n_rec, hdr.data(), ids.data()))) return fail(rc, e->err);
+        mirror_elems = g.size(); dirty.clear();
+        return HX_OK;
+    }
 
     // Runs tasks to completion in lock-step: every round, every live task's request goes into ONE distance launch
     // and ONE pair launch.  At most `window` tasks are live at a time; finished ones are replaced from the rest of
@@ -714,25 +748,59 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
     if (!ix) return HX_E_ARG;
     BatchState &bs = ix->bs; Graph &g = ix->g;
     if (!bs.open || lo > hi || hi > bs.b) return ix->fail(HX_E_STATE, "no open batch / bad member range");
+    std::vector<uint32_t> todo;                                  // batch members still to be searched by the lock-step path
+    if (ix->fused_ok() && hi > lo) {
+        int rc = ix->sync_mirror();
+        if (rc) return rc;
+        const uint32_t n = hi - lo, lm0 = 2u * (uint32_t)g.m;
+        std::vector<uint32_t> qsel(n), status(n), ocnt((size_t)n * HX_FUSED_MAXL), oids((size_t)n * HX_FUSED_MAXL * lm0);
+        std::vector<int32_t> tl(n); std::vector<float> od((size_t)n * HX_FUSED_MAXL * lm0);
+        for (uint32_t i = 0; i < n; i++) { qsel[i] = bs.base + lo + i; tl[i] = g.level[bs.base + lo + i]; }
+        uint64_t cnts[2] = {0, 0};
+        auto t0 = std::chrono::steady_clock::now();
+        if ((rc = ix->e->fused_run(1, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
+                                   oids.data(), od.data(), ocnt.data(), status.data(), cnts))) return ix->fail(rc, ix->e->err);
+        ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ix->counters[1] += cnts[0]; ix->counters[2] += cnts[1];
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t id = bs.base + lo + i;
+            if (status[i] != 0) { todo.push_back(lo + i); continue; }
+            for (int lc = 0; lc <= g.level[id]; lc++) {
+                const uint32_t c = ocnt[(size_t)i * HX_FUSED_MAXL + lc]; Cand *lst = g.list(id, lc);
+                const size_t ob = ((size_t)i * HX_FUSED_MAXL + lc) * lm0;
+                for (uint32_t k = 0; k < c; k++) lst[k] = Cand{od[ob + k], oids[ob + k]};
+                g.cnt(id, lc) = (uint16_t)c;
+            }
+            ix->mark_dirty(id);
+            bs.searched[lo + i] = 1;
+        }
+        ix->fused_tasks += n; ix->fused_redo += todo.size();
+        if (todo.empty()) return HX_OK;
+    } else {
+        for (uint32_t i = lo; i < hi; i++) todo.push_back(i);
+    }
     std::vector<std::unique_ptr<InsertTask>> &its = ix->insert_pool;
-    while (its.size() < hi - lo) its.emplace_back(new InsertTask());
-    std::vector<LsTask *> tasks(hi - lo);
-    for (uint32_t i = lo; i < hi; i++) {
-        InsertTask &t = *its[i - lo];
+    while (its.size() < todo.size()) its.emplace_back(new InsertTask());
+    std::vector<LsTask *> tasks(todo.size());
+    for (size_t ti = 0; ti < todo.size(); ti++) {
+        const uint32_t i = todo[ti];
+        InsertTask &t = *its[ti];
         t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
         t.g = &g; t.id = bs.base + i; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
-        tasks[i - lo] = &t;
+        tasks[ti] = &t;
     }
     int rc = ix->run_lockstep(tasks);
     if (rc) return rc;
-    for (uint32_t i = lo; i < hi; i++) {                        // elements[new_idx].neighbors[lc].items = neighbors (mod.rs:422)
-        InsertTask &t = *its[i - lo];
+    for (size_t ti = 0; ti < todo.size(); ti++) {               // elements[new_idx].neighbors[lc].items = neighbors (mod.rs:422)
+        const uint32_t i = todo[ti];
+        InsertTask &t = *its[ti];
         for (int lc = 0; lc <= t.new_level; lc++) {
             Cand *lst = g.list(t.id, lc);
             for (size_t k = 0; k < t.nb[lc].size(); k++) lst[k] = t.nb[lc][k];
             g.cnt(t.id, lc) = (uint16_t)t.nb[lc].size();
         }
         ix->counters[1] += t.n_dist; ix->counters[2] += t.n_pair;
+        ix->mark_dirty(t.id);
         bs.searched[i] = 1;
     }
     return HX_OK;
@@ -774,7 +842,7 @@ int hx_index_batch_import_new(hx_index *ix, uint32_t lo, uint32_t hi, const void
 {
     if (!ix || !buf || !ix->bs.open || lo > hi || hi > ix->bs.b) return HX_E_ARG;
     const uint8_t *p = (const uint8_t *)buf;
-    for (uint32_t i = lo; i < hi; i++) { for (int lc = 0; lc <= ix->g.level[ix->bs.base + i]; lc++) p = get_list(ix->g, ix->bs.base + i, lc, p); ix->bs.searched[i] = 1; }
+    for (uint32_t i = lo; i < hi; i++) { for (int lc = 0; lc <= ix->g.level[ix->bs.base + i]; lc++) p = get_list(ix->g, ix->bs.base + i, lc, p); ix->bs.searched[i] = 1; ix->mark_dirty(ix->bs.base + i); }
     return HX_OK;
 }
 
@@ -837,7 +905,7 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         btasks.push_back(&bt);
     }
     if ((rc = ix->run_lockstep(btasks))) return rc;
-    for (size_t i = 0; i < nbt; i++) ix->counters[3] += bts[i]->n_pair;
+    for (size_t i = 0; i < nbt; i++) { ix->counters[3] += bts[i]->n_pair; ix->dirty.emplace_back(bts[i]->target, bts[i]->layer); }
     bs.linked = true;
     return HX_OK;
 }
@@ -861,7 +929,7 @@ int hx_index_batch_import_links(hx_index *ix, uint32_t owner, uint32_t world, co
 {
     if (!ix || !buf || !ix->bs.open || !ix->bs.linked || world == 0) return HX_E_ARG;
     const uint8_t *p = (const uint8_t *)buf;
-    for (const auto &gr : ix->bs.grp) { const BackOp &o = ix->bs.ops[gr.first]; if (o.target % world == owner) p = get_list(ix->g, o.target, o.layer, p); }
+    for (const auto &gr : ix->bs.grp) { const BackOp &o = ix->bs.ops[gr.first]; if (o.target % world == owner) { p = get_list(ix->g, o.target, o.layer, p); ix->dirty.emplace_back(o.target, o.layer); } }
     return HX_OK;
 }
 
@@ -964,6 +1032,16 @@ int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t coun
     Cand *l = g.list(elem, layer);
     for (uint32_t k = 0; k < count; k++) l[k] = Cand{dist[k], ids[k]};
     g.cnt(elem, layer) = (uint16_t)count;
+    ix->dirty.emplace_back(elem, layer);
+    return HX_OK;
+}
+
+int hx_index_set_fused(hx_index *ix, int enabled) { if (!ix) return HX_E_ARG; ix->fused = enabled != 0; return HX_OK; }
+int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone)
+{
+    if (!ix) return HX_E_ARG;
+    if (tasks) *tasks = ix->fused_tasks;
+    if (redone) *redone = ix->fused_redo;
     return HX_OK;
 }
 
@@ -990,20 +1068,57 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
     if (!tids_out || !counts_out) return ix->fail(HX_E_ARG, "NULL argument");
     if (ef_search < 1 || ef_search > 1000) return ix->fail(HX_E_ARG, "hnsw.ef_search must be between 1 and 1000");   // options.rs:156-166
     if (nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
-    std::vector<std::unique_ptr<QueryTask>> &qs = ix->query_pool; std::vector<LsTask *> tasks(nq);
-    while (qs.size() < nq) qs.emplace_back(new QueryTask());
-    for (uint32_t q = 0; q < nq; q++) {
-        QueryTask &t = *qs[q];
+    std::vector<uint32_t> todo;                                  // query slots for the lock-step path
+    if (mode == 0 && ix->fused_ok() && ix->g.entry >= 0) {
+        int rc = ix->sync_mirror();
+        if (rc) return rc;
+        const Graph &g = ix->g;
+        const uint32_t ke = std::min<uint32_t>(limit, ef_search);
+        std::vector<uint32_t> qsel(nq), status(nq), ocnt(nq), oids((size_t)nq * ke);
+        std::vector<float> od((size_t)nq * ke);
+        for (uint32_t q = 0; q < nq; q++) qsel[q] = HX_QUERY_SLOT | q;
+        uint64_t cnts[2] = {0, 0};
+        auto t0 = std::chrono::steady_clock::now();
+        if ((rc = ix->e->fused_run(0, nq, qsel.data(), nullptr, ef_search, ke, (uint32_t)g.entry, g.level[g.entry],
+                                   oids.data(), od.data(), ocnt.data(), status.data(), cnts))) return ix->fail(rc, ix->e->err);
+        ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ix->counters[4] += cnts[0];
+        for (uint32_t q = 0; q < nq; q++) {
+            if (status[q] != 0) { todo.push_back(q); continue; }
+            uint32_t c = 0;                                      // amgettuple: every heap TID of each element, nearest first (scan.rs:794-875)
+            for (uint32_t i = 0; i < ocnt[q] && c < limit; i++) {
+                const uint32_t el = oids[(size_t)q * ke + i];
+                for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
+                    tids_out[(size_t)q * limit + c] = g.tids[el][t];
+                    if (dist_out) dist_out[(size_t)q * limit + c] = od[(size_t)q * ke + i];
+                    if (elems_out) elems_out[(size_t)q * limit + c] = el;
+                    c++;
+                }
+            }
+            counts_out[q] = c;
+        }
+        ix->fused_tasks += nq; ix->fused_redo += todo.size();
+        if (todo.empty()) return HX_OK;
+    } else {
+        for (uint32_t q = 0; q < nq; q++) todo.push_back(q);
+    }
+    const uint32_t nt = (uint32_t)todo.size();
+    std::vector<std::unique_ptr<QueryTask>> &qs = ix->query_pool; std::vector<LsTask *> tasks(nt);
+    while (qs.size() < nt) qs.emplace_back(new QueryTask());
+    for (uint32_t qi = 0; qi < nt; qi++) {
+        const uint32_t q = todo[qi];
+        QueryTask &t = *qs[qi];
         t.st = QueryTask::Q_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req(); t.tuples = 0; t.previous_distance = -HUGE_VAL;
         t.out_tid.clear(); t.out_d.clear(); t.out_elem.clear(); t.discarded.clear(); t.results.clear();
         t.g = &ix->g; t.slot = q; t.ef_search = ef_search; t.mode = mode; t.max_scan_tuples = max_scan_tuples; t.limit = limit;
         t.filter = filter; t.n_filter = n_filter;
-        tasks[q] = &t;
+        tasks[qi] = &t;
     }
     int rc = ix->run_lockstep(tasks);
     if (rc) return rc;
-    for (uint32_t q = 0; q < nq; q++) {
-        QueryTask &t = *qs[q];
+    for (uint32_t qi = 0; qi < nt; qi++) {
+        const uint32_t q = todo[qi];
+        QueryTask &t = *qs[qi];
         const uint32_t c = (uint32_t)t.out_tid.size();
         counts_out[q] = c;
         for (uint32_t k = 0; k < c; k++) {

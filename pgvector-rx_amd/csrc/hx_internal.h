@@ -8,6 +8,8 @@
 
 #include "../../include/hnswrx.h"
 
+#define HX_FUSED_MAXL 8   /* layers handled by the fused kernel; mirrors FUSED_MAXL */
+
 // One request channel = ONE pinned host buffer + ONE device mirror for everything a lock-step round sends
 // (group query selectors, offsets, row ids, pair-group descriptors, workgroup table) and ONE pair of buffers for
 // what it gets back (K1 distances, K2 pair distances): a round costs one H2D copy, <= 2 kernels, one D2H copy,
@@ -35,6 +37,16 @@ struct HxChannel {
 
 struct HxKernelStat { uint64_t launches = 0, units = 0; double ms = 0.0; };
 
+// device copy of the graph (neighbour ids only) + scratch of the fused traversal kernel (hx_fused.inc.h)
+struct HxMirror {
+    uint32_t m = 0; uint64_t cap = 0, cap_blocks = 0;
+    uint32_t *d_l0_ids = nullptr; uint16_t *d_l0_cnt = nullptr; int32_t *d_level = nullptr;
+    uint32_t *d_up_block = nullptr, *d_up_ids = nullptr; uint16_t *d_up_cnt = nullptr;
+    uint32_t *d_vis = nullptr; uint64_t cap_vis = 0;
+    uint8_t *h_stage = nullptr, *d_stage = nullptr; size_t cap_stage = 0;
+    uint8_t *h_io = nullptr, *d_io = nullptr; size_t cap_io = 0;
+};
+
 struct hx_engine {
     int device = 0, dtype = 0, metric = 0, dim = 0;
     uint64_t row_bytes = 0, pitch = 0, capacity = 0, n_rows = 0;
@@ -43,7 +55,8 @@ struct hx_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timing = false; float last_ms = 0.f;
-    HxKernelStat stat_dist, stat_pair;
+    HxKernelStat stat_dist, stat_pair, stat_fused;
+    HxMirror mirror;
     HxChannel ch;
     std::string err;
 
@@ -51,6 +64,13 @@ struct hx_engine {
     // then (after the caller filled the h_* request arrays) copy, launch K1 and/or K2, copy back, sync.
     int layout_round(const HxRound &r);
     int run_round();
+    // device-resident traversal (hx_fused.inc.h)
+    int mirror_reserve(uint32_t m, uint64_t n_elems, uint64_t n_blocks);
+    int mirror_update(uint32_t first, uint32_t n_new, const int32_t *levels, const uint32_t *blocks,
+                      uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids);
+    int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
+                  uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
+                  uint64_t counts[2]);
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 

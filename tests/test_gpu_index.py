@@ -23,11 +23,12 @@ def make_rows(dtype, n, dim, rng):
     return np.packbits(rng.integers(0, 2, (n, dim)).astype(np.uint8), axis=1, bitorder="big")
 
 
-def build_both(dtype, metric, dim, rows, levels, m, efc, batch):
+def build_both(dtype, metric, dim, rows, levels, m, efc, batch, fused=True):
     n = len(levels)
     e = hx.Engine(dtype, metric, dim, n)
     e.append(rows)
     ix = hx.Index(e, m, efc)
+    ix.set_fused(fused)
     elem = ix.insert(0, levels, batch=batch)
     o = orc.Index(dtype, metric, dim, m=m, ef_construction=efc, order=orc.W64)
     tids = np.arange(n, dtype=np.int64)
@@ -70,15 +71,20 @@ CASES = [
 
 @pytest.mark.parametrize("dtype,metric,dim,n,m,efc", CASES)
 @pytest.mark.parametrize("batch", [1, 37])
-def test_graph_identical_to_oracle(dtype, metric, dim, n, m, efc, batch):
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "lockstep"])
+def test_graph_identical_to_oracle(dtype, metric, dim, n, m, efc, batch, fused):
+    """fused = the device-resident traversal kernel (hx_fused.inc.h); lockstep = the host driver.  Both must
+    reproduce the oracle's graph and result lists bit for bit."""
     rng = np.random.default_rng(dim * 7 + batch)
     rows = make_rows(dtype, n, dim, rng)
     rows[50] = rows[10]           # duplicates exercise build.rs:482-512
     rows[51] = rows[10]
     levels = hx.draw_levels(n, m, seed=4)
-    e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, batch)
+    e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, batch, fused)
     assert elem.tolist() == oelem.tolist()
     assert_same_graph(ix, o, n)
+    st = ix.fused_stats()
+    assert (st["tasks"] > 0) == fused and st["redone"] <= st["tasks"] // 10
     # search parity: same tids, same distances (bits), same order, incl. ties
     nq, efs, k = 40, 40, 10
     qs = make_rows(dtype, nq, dim, rng)
