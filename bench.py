@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--cpu-build-rows", type=int, default=1500)
     p.add_argument("--cpu-queries", type=int, default=300)
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-fused", action="store_true", help="run every traversal in the lock-step host driver")
     return p.parse_args()
 
 
@@ -117,6 +118,8 @@ def main():
     if a.threads:
         ix.set_threads(a.threads)
     eng.set_timing(True)
+    if a.no_fused:
+        ix.set_fused(False)
 
     # ---- build (timed once; barrier + sync on both sides; max over ranks) ----
     barrier()
@@ -132,7 +135,7 @@ def main():
         t = torch.tensor([build_sec], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         build_sec = float(t.item())
-    build_stats = {"dist": eng.kernel_stats(0, reset=True), "pair": eng.kernel_stats(1, reset=True)}
+    build_stats = {"dist": eng.kernel_stats(0, reset=True), "pair": eng.kernel_stats(1, reset=True), "fused": eng.kernel_stats(2, reset=True)}
     counters = ix.counters()
     build_prof = ix.profile(reset=True)
 
@@ -141,6 +144,7 @@ def main():
     for _ in range(a.warmup):
         ix.search(a.queries, a.efs, a.k)
     warm_stat = eng.kernel_stats(0, reset=True)
+    warm_fused = eng.kernel_stats(2, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -152,6 +156,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     sstat = eng.kernel_stats(0)
+    fstat = eng.kernel_stats(2)
     search_prof = ix.profile()
     qps = world * a.queries * a.steps / dt
 
@@ -175,7 +180,17 @@ def main():
                 "frac": round(k1_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
                 "launches": sstat["launches"], "avg_launch_ms": round(k1_ms, 4),
                 "distances_per_launch": round(sstat["units"] / max(1, sstat["launches"]), 1), "bytes_per_distance": row_bytes}
+    if fstat["launches"]:
+        # the timed region ran in the device-resident traversal kernel: it is the dominant kernel, and every distance it
+        # evaluates streams one row from HBM exactly like K1 does
+        f_ms = fstat["ms"] / fstat["launches"]
+        f_gbps = fstat["units"] * row_bytes / max(fstat["ms"], 1e-9) / 1e6
+        roofline = {"bound": "hbm", "kernel": "k_fused<query>", "achieved": round(f_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(f_gbps / HBM_PEAK_GBPS, 4), "traffic": None, "launches": fstat["launches"],
+                    "avg_launch_ms": round(f_ms, 3), "distances_per_launch": round(fstat["units"] / fstat["launches"], 1),
+                    "bytes_per_distance": row_bytes}
     bd, bp = build_stats["dist"], build_stats["pair"]
+    bf = build_stats["fused"]
     # every K1 launch of this process (build + warmup + timed steps): the figure a `rocprofv3 --kernel-trace --stats`
     # run of this same command reports as the kernel's average duration
     all_l = bd["launches"] + warm_stat["launches"] + sstat["launches"]
@@ -185,6 +200,8 @@ def main():
     build_kernels = {
         "k_dist_groups": {"launches": bd["launches"], "distances": bd["units"], "ms": round(bd["ms"], 1),
                           "GBps": round(bd["units"] * row_bytes / max(bd["ms"], 1e-9) / 1e6, 1)},
+        "k_fused<insert>": {"launches": bf["launches"], "distances": bf["units"], "ms": round(bf["ms"], 1),
+                            "GBps": round(bf["units"] * row_bytes / max(bf["ms"], 1e-9) / 1e6, 1)},
         "k_pair_groups": {"launches": bp["launches"], "pairs": bp["units"], "ms": round(bp["ms"], 1),
                           "Gpairs_per_s": round(bp["units"] / max(bp["ms"], 1e-9) / 1e6, 2)},
     }
@@ -238,6 +255,7 @@ def main():
         "cpu_baseline": cpu,
         "build_kernels": build_kernels,
         "host_profile": {"build": {k: round(v, 2) for k, v in build_prof.items()}, "search_all_steps": {k: round(v, 3) for k, v in search_prof.items()}},
+        "fused": ix.fused_stats(),
         "build_distance_evals": {"search": int(counters[1]), "select": int(counters[2]), "backlink": int(counters[3])},
     }
     print(json.dumps(out), flush=True)
