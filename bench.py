@@ -135,7 +135,7 @@ def main():
         t = torch.tensor([build_sec], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         build_sec = float(t.item())
-    build_stats = {"dist": eng.kernel_stats(0, reset=True), "pair": eng.kernel_stats(1, reset=True), "fused": eng.kernel_stats(2, reset=True)}
+    build_stats = {"dist": eng.kernel_stats(0, reset=True), "pair": eng.kernel_stats(1, reset=True), "fused": eng.kernel_stats(2, reset=True), "links": eng.kernel_stats(3, reset=True)}
     counters = ix.counters()
     build_prof = ix.profile(reset=True)
 
@@ -191,6 +191,7 @@ def main():
                     "bytes_per_distance": row_bytes}
     bd, bp = build_stats["dist"], build_stats["pair"]
     bf = build_stats["fused"]
+    bl = build_stats["links"]
     # every K1 launch of this process (build + warmup + timed steps): the figure a `rocprofv3 --kernel-trace --stats`
     # run of this same command reports as the kernel's average duration
     all_l = bd["launches"] + warm_stat["launches"] + sstat["launches"]
@@ -202,6 +203,8 @@ def main():
                           "GBps": round(bd["units"] * row_bytes / max(bd["ms"], 1e-9) / 1e6, 1)},
         "k_fused<insert>": {"launches": bf["launches"], "distances": bf["units"], "ms": round(bf["ms"], 1),
                             "GBps": round(bf["units"] * row_bytes / max(bf["ms"], 1e-9) / 1e6, 1)},
+        "k_links": {"launches": bl["launches"], "pairs": bl["units"], "ms": round(bl["ms"], 1),
+                    "Gpairs_per_s": round(bl["units"] / max(bl["ms"], 1e-9) / 1e6, 2)},
         "k_pair_groups": {"launches": bp["launches"], "pairs": bp["units"], "ms": round(bp["ms"], 1),
                           "Gpairs_per_s": round(bp["units"] / max(bp["ms"], 1e-9) / 1e6, 2)},
     }

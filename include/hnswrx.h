@@ -207,8 +207,9 @@ int hx_index_set_fused(hx_index *ix, int enabled);
 int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone);
 
 /* host-side wall time of the lock-step driver since the last reset, seconds: [0] task state machines,
- * [1] request compaction, [2] request fill, [3] round copies+launches+wait, [4] unused, [5] rounds, [6] fused kernel calls */
-int hx_index_profile(const hx_index *ix, double seconds_out[8], int reset);
+ * [1] request compaction, [2] request fill, [3] round copies+launches+wait, [4] unused, [5] rounds, [6] fused kernel calls, [7] mirror sync, [8] link-stage setup, [9] link-stage lock-step, [10] hx_index_insert total,
+ * [11] batch_search total, [12] batch_begin total */
+int hx_index_profile(const hx_index *ix, double seconds_out[16], int reset);
 
 /* get_scan_items + amgettuple (scan.rs:458-530, 709-876), iterative_scan = off, for nq queries in
  * lock-step: the queries are the engine's query slots 0..nq-1 (hx_set_queries).  Per query, up to k heap

@@ -356,9 +356,11 @@ class Index:
         return c
 
     def profile(self, reset=False):
-        p = np.zeros(8, np.float64)
+        p = np.zeros(16, np.float64)
         self._ck(lib().hx_index_profile(self.h, _p(p), int(reset)))
-        return {"advance_s": p[0], "compact_s": p[1], "fill_s": p[2], "round_s": p[3], "rounds": int(p[5]), "fused_s": p[6]}
+        return {"advance_s": p[0], "compact_s": p[1], "fill_s": p[2], "round_s": p[3], "rounds": int(p[5]), "fused_s": p[6],
+                "mirror_sync_s": p[7], "links_setup_s": p[8], "links_lockstep_s": p[9], "insert_total_s": p[10],
+                "batch_search_s": p[11], "batch_begin_s": p[12]}
 
     def set_fused(self, on):
         self._ck(lib().hx_index_set_fused(self.h, int(on)))

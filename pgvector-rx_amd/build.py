@@ -15,10 +15,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 
 def stale():
+    """True when the library is missing or older than ANY file under csrc/ or include/."""
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    inc = os.path.join(HERE, "..", "include")
+    deps += [os.path.join(inc, f) for f in os.listdir(inc)]
+    return any(os.path.getmtime(f) > t for f in deps)
 
 
 def build(force=False, verbose=False):

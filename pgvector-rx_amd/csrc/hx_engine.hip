@@ -75,6 +75,8 @@ template <int KIND> struct OpF32 {
         float s = lanes_sum_f<LPR>(acc);
         return KIND == K_IP ? -s : s;      // vector_negative_inner_product, vector.rs:631
     }
+    static constexpr bool kFloatAcc = true;
+    static __device__ __forceinline__ float post(float s) { return KIND == K_IP ? -s : s; }
 };
 
 template <int KIND> struct OpF16 {
@@ -93,6 +95,8 @@ template <int KIND> struct OpF16 {
         float s = lanes_sum_f<LPR>(acc);
         return KIND == K_IP ? -s : s;
     }
+    static constexpr bool kFloatAcc = true;
+    static __device__ __forceinline__ float post(float s) { return KIND == K_IP ? -s : s; }
 };
 
 struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
@@ -104,6 +108,8 @@ struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
         for (int t = 0; t < 4; t++) acc += __popc(a[t] ^ b[t]);
     }
     template <int LPR> static __device__ __forceinline__ float finish(acc_t acc) { return (float)lanes_sum_i<LPR>(acc); }
+    static constexpr bool kFloatAcc = false;
+    static __device__ __forceinline__ float post(float s) { return s; }
 };
 
 struct JacAcc { int ab, aa, bb; };
@@ -121,6 +127,8 @@ struct OpJaccard {   // bitvec.rs:113-132
         double d = ab == 0 ? 1.0 : 1.0 - ((double)ab / (double)(aa + bb - ab));
         return (float)d;                   // f64 result, `as f32` on the build path (build.rs:367)
     }
+    static constexpr bool kFloatAcc = false;
+    static __device__ __forceinline__ float post(float s) { return s; }
 };
 
 // =================================================================================================
@@ -176,6 +184,48 @@ k_dist_groups(const uint8_t *__restrict__ rows, const uint8_t *__restrict__ quer
         for (int k = 0; k < RIF; k++) {
             float d = OP::template finish<LPR>(acc[k]);
             if (sl == 0 && ridx[k] < n) out[beg + ridx[k]] = d;
+        }
+    }
+}
+
+// 64 butterflies at once: a[s] is this lane's partial of pair s (s < 64).  Stage k exchanges half of the live values
+// across lanes l <-> l^off and adds, halving the number of live registers; every add has exactly the two operands the
+// plain xor butterfly of that pair has at that stage (p[l] + p[l^off], commutative), so the sums are the same bits.
+// Returns, in lane l, the full sum of pair l.  63 cross-lane moves instead of 64*6.
+template <int N> __device__ __forceinline__ void xstage(const float (&in)[2 * N], float (&out)[N], uint32_t lane, int off)
+{
+    const bool up = (lane & (uint32_t)off) != 0;
+#pragma unroll
+    for (int s = 0; s < N; s++) {
+        const float lo = in[s], hi = in[s + N];
+        const float send = up ? lo : hi, keep = up ? hi : lo;
+        out[s] = keep + __shfl_xor(send, off, 64);
+    }
+}
+__device__ __forceinline__ float reduce64_transposed(const float (&a)[64], uint32_t lane)
+{
+    float v32[32], v16[16], v8[8], v4[4], v2[2], v1[1];
+    xstage<32>(a, v32, lane, 32); xstage<16>(v32, v16, lane, 16); xstage<8>(v16, v8, lane, 8);
+    xstage<4>(v8, v4, lane, 4); xstage<2>(v4, v2, lane, 2); xstage<1>(v2, v1, lane, 1);
+    return v1[0];
+}
+// results of a wave's HX_PAIRS_PER_WAVE accumulators: res0 = pair `lane` (< 64), res1 = pair 64+lane (lanes 0,1)
+template <class OP, int NP>
+__device__ __forceinline__ void reduce_pairs(typename OP::acc_t (&acc)[NP], uint32_t lane, float &res0, float &res1)
+{
+    res0 = 0.0f; res1 = 0.0f;
+    if constexpr (OP::kFloatAcc && NP >= 64) {
+        float a[64];
+#pragma unroll
+        for (int s = 0; s < 64; s++) a[s] = acc[s];
+        res0 = OP::post(reduce64_transposed(a, lane));
+#pragma unroll
+        for (int s = 64; s < NP; s++) { const float d = OP::template finish<64>(acc[s]); if (lane == (uint32_t)(s - 64)) res1 = d; }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NP; s++) {
+            const float d = OP::template finish<64>(acc[s]);
+            if (s < 64) { if (lane == (uint32_t)s) res0 = d; } else { if (lane == (uint32_t)(s - 64)) res1 = d; }
         }
     }
 }
@@ -275,13 +325,8 @@ k_pair_groups(const uint8_t *__restrict__ rows, uint32_t pitch,
         }
     }
     if (!active) return;
-    float res0 = 0.0f, res1 = 0.0f;
-#pragma unroll
-    for (int s = 0; s < HX_PAIRS_PER_WAVE; s++) {
-        float d = OP::template finish<64>(acc[s]);
-        if (s < 64) { if (lane == (uint32_t)s) res0 = d; }
-        else { if (lane == (uint32_t)(s - 64)) res1 = d; }
-    }
+    float res0, res1;
+    reduce_pairs<OP, HX_PAIRS_PER_WAVE>(acc, lane, res0, res1);
     const uint64_t ob = pg_out_off[g];
     if (pw0 + lane < P) out[ob + pw0 + lane] = res0;
     if (lane < HX_PAIRS_PER_WAVE - 64 && pw0 + 64 + lane < P) out[ob + pw0 + 64 + lane] = res1;
@@ -577,8 +622,8 @@ int hx_destroy(hx_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     HxChannel &c = e->ch;
     HxMirror &mr = e->mirror;
-    void *hp[] = {c.h_req, c.h_res, mr.h_stage, mr.h_io};
-    void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries, mr.d_l0_ids, mr.d_l0_cnt, mr.d_level, mr.d_up_block, mr.d_up_ids, mr.d_up_cnt, mr.d_vis, mr.d_stage, mr.d_io};
+    void *hp[] = {c.h_req, c.h_res, mr.h_stage, mr.h_io, mr.h_lk};
+    void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries, mr.d_l0_ids, mr.d_l0_d, mr.d_l0_cnt, mr.d_level, mr.d_up_block, mr.d_up_ids, mr.d_up_d, mr.d_up_cnt, mr.d_vis, mr.d_stage, mr.d_io, mr.d_lk};
     for (void *p : hp) if (p) (void)hipHostFree(p);
     for (void *p : dp) if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -847,7 +892,7 @@ int hx_last_kernel_ms(hx_engine *e, float *ms) { if (!e || !ms) return HX_E_ARG;
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset)
 {
     if (!e) return HX_E_ARG;
-    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : e->stat_fused;
+    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : kind == 2 ? e->stat_fused : e->stat_links;
     if (launches) *launches = s.launches;
     if (units) *units = s.units;
     if (ms) *ms = s.ms;

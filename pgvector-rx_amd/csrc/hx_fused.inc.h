@@ -353,19 +353,19 @@ __global__ void k_mirror_levels(int32_t *level, uint32_t *up_block, uint32_t fir
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { level[first + i] = lv[i]; up_block[first + i] = blk[i]; }
 }
-// one 64-thread block per record: {elem, layer, cnt, block} + ids[stride]
-__global__ void k_mirror_lists(uint32_t *l0_ids, uint16_t *l0_cnt, uint32_t *up_ids, uint16_t *up_cnt, uint32_t m,
-                               uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids, uint32_t stride)
+// one 64-thread block per record: {elem, layer, cnt, block} + ids[stride] + dists[stride]
+__global__ void k_mirror_lists(uint32_t *l0_ids, float *l0_d, uint16_t *l0_cnt, uint32_t *up_ids, float *up_d, uint16_t *up_cnt, uint32_t m,
+                               uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids, const float *dd, uint32_t stride)
 {
     const uint32_t r = blockIdx.x;
     if (r >= n_rec) return;
     const uint32_t elem = hdr[4 * r], layer = hdr[4 * r + 1], cnt = hdr[4 * r + 2], blk = hdr[4 * r + 3];
-    const uint32_t *src = ids + (size_t)r * stride;
+    const uint32_t *src = ids + (size_t)r * stride; const float *sd = dd + (size_t)r * stride;
     if (layer == 0) {
-        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) l0_ids[(size_t)elem * 2u * m + k] = src[k];
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) { l0_ids[(size_t)elem * 2u * m + k] = src[k]; l0_d[(size_t)elem * 2u * m + k] = sd[k]; }
         if (threadIdx.x == 0) l0_cnt[elem] = (uint16_t)cnt;
     } else {
-        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) up_ids[(size_t)blk * m + k] = src[k];
+        for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) { up_ids[(size_t)blk * m + k] = src[k]; up_d[(size_t)blk * m + k] = sd[k]; }
         if (threadIdx.x == 0) up_cnt[blk] = (uint16_t)cnt;
     }
 }
@@ -391,6 +391,7 @@ int hx_engine::mirror_reserve(uint32_t m, uint64_t n_elems, uint64_t n_blocks)
     if (n_elems > mr.cap) {
         const uint64_t nc = std::max<uint64_t>(std::max<uint64_t>(n_elems, capacity), mr.cap * 2);
         if ((rc = mirror_grow(this, mr.d_l0_ids, mr.cap * 2 * m, nc * 2 * m))) return rc;
+        if ((rc = mirror_grow(this, mr.d_l0_d, mr.cap * 2 * m, nc * 2 * m))) return rc;
         if ((rc = mirror_grow(this, mr.d_l0_cnt, mr.cap, nc))) return rc;
         if ((rc = mirror_grow(this, mr.d_level, mr.cap, nc))) return rc;
         if ((rc = mirror_grow(this, mr.d_up_block, mr.cap, nc))) return rc;
@@ -399,19 +400,20 @@ int hx_engine::mirror_reserve(uint32_t m, uint64_t n_elems, uint64_t n_blocks)
     if (n_blocks > mr.cap_blocks) {
         const uint64_t nb = std::max<uint64_t>(std::max<uint64_t>(n_blocks, capacity / 8 + 1024), mr.cap_blocks * 2);
         if ((rc = mirror_grow(this, mr.d_up_ids, mr.cap_blocks * m, nb * m))) return rc;
+        if ((rc = mirror_grow(this, mr.d_up_d, mr.cap_blocks * m, nb * m))) return rc;
         if ((rc = mirror_grow(this, mr.d_up_cnt, mr.cap_blocks, nb))) return rc;
         mr.cap_blocks = nb;
     }
     return HX_OK;
 }
 
-// levels/up_block of elements [first, first+n_new) and n_rec list records (hdr: elem, layer, cnt, block; ids: stride 2m)
+// levels/up_block of elements [first, first+n_new) and n_rec list records (hdr: elem, layer, cnt, block; ids, dists: stride 2m)
 int hx_engine::mirror_update(uint32_t first, uint32_t n_new, const int32_t *levels, const uint32_t *blocks,
-                             uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids)
+                             uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids, const float *dists)
 {
     HxMirror &mr = mirror;
     const uint32_t stride = 2 * mr.m;
-    const size_t bytes = (size_t)n_new * 8 + (size_t)n_rec * (16 + (size_t)stride * 4);
+    const size_t bytes = (size_t)n_new * 8 + (size_t)n_rec * (16 + (size_t)stride * 8);
     if (bytes == 0) return HX_OK;
     if (bytes > mr.cap_stage) {
         if (mr.h_stage) (void)hipHostFree(mr.h_stage);
@@ -427,13 +429,261 @@ int hx_engine::mirror_update(uint32_t first, uint32_t n_new, const int32_t *leve
     const size_t o_bk = o; memcpy(h + o, blocks, (size_t)n_new * 4); o += (size_t)n_new * 4;
     const size_t o_hdr = o; memcpy(h + o, hdr, (size_t)n_rec * 16); o += (size_t)n_rec * 16;
     const size_t o_ids = o; memcpy(h + o, ids, (size_t)n_rec * stride * 4); o += (size_t)n_rec * stride * 4;
+    const size_t o_dd = o; memcpy(h + o, dists, (size_t)n_rec * stride * 4); o += (size_t)n_rec * stride * 4;
     HX_HIP(this, hipMemcpyAsync(mr.d_stage, h, o, hipMemcpyHostToDevice, stream));
     if (n_new) hipLaunchKernelGGL(k_mirror_levels, dim3((n_new + 255) / 256), dim3(256), 0, stream, mr.d_level, mr.d_up_block, first, n_new,
                                   (const int32_t *)(mr.d_stage + o_lv), (const uint32_t *)(mr.d_stage + o_bk));
-    if (n_rec) hipLaunchKernelGGL(k_mirror_lists, dim3(n_rec), dim3(64), 0, stream, mr.d_l0_ids, mr.d_l0_cnt, mr.d_up_ids, mr.d_up_cnt, mr.m, n_rec,
-                                  (const uint32_t *)(mr.d_stage + o_hdr), (const uint32_t *)(mr.d_stage + o_ids), stride);
+    if (n_rec) hipLaunchKernelGGL(k_mirror_lists, dim3(n_rec), dim3(64), 0, stream, mr.d_l0_ids, mr.d_l0_d, mr.d_l0_cnt, mr.d_up_ids, mr.d_up_d, mr.d_up_cnt, mr.m, n_rec,
+                                  (const uint32_t *)(mr.d_stage + o_hdr), (const uint32_t *)(mr.d_stage + o_ids), (const float *)(mr.d_stage + o_dd), stride);
     HX_HIP(this, hipGetLastError());
     HX_HIP(this, hipStreamSynchronize(stream));
+    return HX_OK;
+}
+
+// =================================================================================================
+// K3 k_links: update_neighbor_connections (graph/mod.rs:442-489) for one (target, layer) list per 512-thread workgroup.
+//   The list (ids + distances) comes from the device mirror into LDS; the group's back-link ops are applied in
+//   insertion order: append while there is room (mod.rs:469-471); otherwise candidates = list + new, stable sort by
+//   distance (rank sort), the <= 33 candidate rows are staged through LDS exactly as in K2 (1 KiB chunks, register
+//   prefetch, double buffer) to form the lower-triangular pair matrix in LDS, and one wavefront runs
+//   select_neighbors / check_element_closer (mod.rs:269-339) on that matrix.  The new list goes back to the mirror
+//   and to the host.  Distances use the canonical order, so the result is bit-identical to the lock-step path.
+// =================================================================================================
+#define LK_MAXN 33            /* lm + 1 with lm <= 32 */
+#define LK_STAGE 5
+
+struct LinksParams {
+    const uint8_t *rows; uint32_t pitch, m;
+    uint32_t *l0_ids; float *l0_d; uint16_t *l0_cnt; const uint32_t *up_block; uint32_t *up_ids; float *up_d; uint16_t *up_cnt;
+    uint32_t n_groups; const uint32_t *target, *layer, *op_off, *op_new; const float *op_d;
+    uint32_t *out_ids; float *out_d; uint32_t *out_cnt; unsigned long long *n_pairs;
+    uint32_t dbg;   // timing experiments only (HX_LK_DBG): 1 skip pair math, 2 skip row loads, 4 skip select
+};
+
+template <class OP>
+__global__ void __launch_bounds__(HX_PAIR_WG, 4)
+k_links(const LinksParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t buf_bytes = LK_MAXN * 1024u;
+    uint8_t *bufs = lds;                                         // 2 x 33 KiB row-chunk buffers
+    uint32_t *lid = (uint32_t *)(lds + 2 * buf_bytes);           // current list ids [40]
+    float *ld = (float *)(lid + 40);                             // current list distances [40]
+    uint32_t *sid = (uint32_t *)(ld + 40);                       // sorted candidates [40]
+    float *sd = (float *)(sid + 40);
+    float *tri = sd + 40;                                        // pair matrix, packed lower triangle [528]
+    uint32_t *sel = (uint32_t *)(tri + HX_PAIR_SLAB);            // R indices [40], discarded indices [40], ctl [8]
+    uint32_t *dis = sel + 40; uint32_t *ctl = dis + 40;
+
+    const uint32_t g = blockIdx.x;
+    if (g >= p.n_groups) return;
+    if (p.dbg & 8u) return;
+    const uint32_t target = p.target[g], layer = p.layer[g];
+    const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
+    if (layer == 0) { gl_ids = p.l0_ids + (size_t)target * 2u * p.m; gl_d = p.l0_d + (size_t)target * 2u * p.m; gl_cnt = p.l0_cnt + target; }
+    else { const uint32_t blk = p.up_block[target] + layer - 1; gl_ids = p.up_ids + (size_t)blk * p.m; gl_d = p.up_d + (size_t)blk * p.m; gl_cnt = p.up_cnt + blk; }
+    uint32_t cnt = *gl_cnt;
+    if (threadIdx.x < cnt) { lid[threadIdx.x] = gl_ids[threadIdx.x]; ld[threadIdx.x] = gl_d[threadIdx.x]; }
+    __syncthreads();
+    unsigned long long pairs = 0;
+
+    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
+        if (p.dbg & 16u) break;
+        const uint32_t new_id = p.op_new[op]; const float new_d = p.op_d[op];
+        if (cnt < lm) {                                                            // mod.rs:469-471
+            if (threadIdx.x == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
+            cnt++;
+            __syncthreads();
+            continue;
+        }
+        const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
+        if (threadIdx.x == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
+        __syncthreads();
+        if (threadIdx.x < n) {
+            const float d = ld[threadIdx.x]; uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) { const float dj = ld[j]; rank += (dj < d) || (dj == d && j < threadIdx.x); }
+            sid[rank] = lid[threadIdx.x]; sd[rank] = d;
+        }
+        __syncthreads();
+        // ---- pair matrix of the n candidate rows.  Rows 1..n-1 of the triangle are paired (r, n-r) -- r + (n-r) = n <= 33
+        // pairs per row-pair -- and wave w owns row-pairs q = w and q = 15 - w (r = q + 1).  For a row-pair, accumulator
+        // A[j] is pair (n-r, j), j < n-r, and A[32-j] is pair (r, j), j < r (disjoint because n <= 33).  A wave reads
+        // its 4 "a" fragments once per chunk and each b_j fragment once for up to 4 pairs: 36 LDS reads per chunk
+        // instead of 132, and 4 independent accumulation chains per read. ----
+        const uint32_t P = n * (n - 1) / 2;
+        uint32_t rr[2], hh[2]; bool use_r[2], use_h[2];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; q2++) {
+            const uint32_t q = q2 == 0 ? wave : 15u - wave;
+            const uint32_t r = q + 1, h = n - r;                   // r <= 16
+            use_h[q2] = r < n && h > r;                            // partner row strictly above r
+            use_r[q2] = r < n && h >= r;                           // r itself (also the lone middle row when h == r)
+            rr[q2] = r; hh[q2] = use_h[q2] ? h : 0u;
+        }
+        uint32_t rid[LK_STAGE];
+#pragma unroll
+        for (int t = 0; t < LK_STAGE; t++) { const uint32_t r = wave + t * HX_PAIR_WAVES; rid[t] = r < n ? sid[r] : 0u; }
+        typename OP::acc_t acc[HX_PAIRS_PER_WAVE];                 // [0..32] row-pair 0, [33..65] row-pair 1
+#pragma unroll
+        for (int s2 = 0; s2 < HX_PAIRS_PER_WAVE; s2++) OP::init(acc[s2]);
+        u4 pre[LK_STAGE];
+        auto prefetch = [&](uint32_t c0) {
+            const uint32_t off = c0 + lane * 16u;
+#pragma unroll
+            for (int t = 0; t < LK_STAGE; t++) {
+                u4 v = {0u, 0u, 0u, 0u};
+                if (wave + t * HX_PAIR_WAVES < n && off < p.pitch && !(p.dbg & 2u)) v = *(const u4 *)(p.rows + (size_t)rid[t] * p.pitch + off);
+                pre[t] = v;
+            }
+        };
+        prefetch(0);
+        uint32_t bufsel = 0;
+        for (uint32_t c0 = 0; c0 < p.pitch; c0 += 1024u, bufsel ^= 1u) {
+            uint8_t *buf = bufs + bufsel * buf_bytes;
+#pragma unroll
+            for (int t = 0; t < LK_STAGE; t++) {
+                const uint32_t r = wave + t * HX_PAIR_WAVES;
+                if (r < n) *(u4 *)(buf + r * 1024u + lane * 16u) = pre[t];
+            }
+            __syncthreads();
+            if (c0 + 1024u < p.pitch) prefetch(c0 + 1024u);
+            if (p.dbg & 1u) continue;
+            const u4 ar0 = *(const u4 *)(buf + rr[0] * 1024u + lane * 16u), ah0 = *(const u4 *)(buf + hh[0] * 1024u + lane * 16u);
+            const u4 ar1 = *(const u4 *)(buf + rr[1] * 1024u + lane * 16u), ah1 = *(const u4 *)(buf + hh[1] * 1024u + lane * 16u);
+            const uint32_t jmax = n - 1u;                          // largest row index any wave needs as "b" is n-2
+#pragma unroll
+            for (int j = 0; j < LK_MAXN - 1; j++) {
+                if ((uint32_t)j < jmax) {
+                    const u4 bj = *(const u4 *)(buf + (uint32_t)j * 1024u + lane * 16u);
+                    if (use_h[0] && (uint32_t)j < hh[0]) OP::add(acc[j], ah0, bj);
+                    if (use_r[0] && (uint32_t)j < rr[0]) OP::add(acc[32 - j], ar0, bj);
+                    if (use_h[1] && (uint32_t)j < hh[1]) OP::add(acc[33 + j], ah1, bj);
+                    if (use_r[1] && (uint32_t)j < rr[1]) OP::add(acc[33 + 32 - j], ar1, bj);
+                }
+            }
+        }
+        {
+            float res0, res1;
+            reduce_pairs<OP, HX_PAIRS_PER_WAVE>(acc, lane, res0, res1);
+            // lane l holds accumulator l (< 64); lanes 0,1 also hold accumulators 64, 65
+#pragma unroll
+            for (int part = 0; part < 2; part++) {
+                const uint32_t sidx = part == 0 ? lane : 64u + lane;
+                const float val = part == 0 ? res0 : res1;
+                if (part == 1 && lane >= HX_PAIRS_PER_WAVE - 64) continue;
+                const uint32_t q2 = sidx >= 33u ? 1u : 0u, k = sidx - 33u * q2;
+                const uint32_t r = q2 ? rr[1] : rr[0], h = q2 ? hh[1] : hh[0];
+                const bool uh = q2 ? use_h[1] : use_h[0], ur = q2 ? use_r[1] : use_r[0];
+                if (uh && k < h) tri[h * (h - 1) / 2 + k] = val;
+                else if (ur && 32u - k < r) tri[r * (r - 1) / 2 + (32u - k)] = val;
+            }
+        }
+        pairs += P;
+        __syncthreads();
+        // ---- select_neighbors(candidates, lm) on the matrix: mod.rs:284-305 ----
+        if (wave == 0) {
+            uint32_t r = 0, nd = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                if (r >= lm) break;                                                // mod.rs:285-287
+                if (p.dbg & 4u) { if (lane == 0) sel[r] = i; r++; continue; }
+                const float ed = sd[i];
+                bool hit = false;
+                if (lane < r) { const uint32_t rj = sel[lane]; hit = tri[i * (i - 1) / 2 + rj] <= ed; }   // mod.rs:333-335
+                const bool closer = __ballot(hit) == 0ull;
+                if (lane == 0) { if (closer) sel[r] = i; else dis[nd] = i; }
+                if (closer) r++; else nd++;
+            }
+            if (lane == 0) { for (uint32_t j = 0; j < nd && r < lm; j++) sel[r++] = dis[j]; ctl[0] = r; }   // mod.rs:300-305
+        }
+        __syncthreads();
+        cnt = ctl[0];
+        if (threadIdx.x < cnt) { const uint32_t k = sel[threadIdx.x]; lid[threadIdx.x] = sid[k]; ld[threadIdx.x] = sd[k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < cnt) {
+        gl_ids[threadIdx.x] = lid[threadIdx.x]; gl_d[threadIdx.x] = ld[threadIdx.x];
+        p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x];
+    }
+    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, pairs); }
+}
+
+template <class OP>
+static hipError_t launch_links(hx_engine *e, const LinksParams &p)
+{
+    const size_t lds = 2 * (size_t)LK_MAXN * 1024u + (40 * 4 + HX_PAIR_SLAB + 40 * 2 + 8) * 4;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t s = hipFuncSetAttribute((const void *)k_links<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (s != hipSuccess) return s;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_links<OP>), dim3(p.n_groups), dim3(HX_PAIR_WG), lds, e->stream, p);
+    return hipGetLastError();
+}
+
+int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
+                         const uint32_t *op_new, const float *op_d, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint64_t *n_pairs)
+{
+    HxMirror &mr = mirror;
+    if (n_groups == 0) return HX_OK;
+    if (2 * mr.m + 1 > LK_MAXN) return fail(HX_E_ARG, "k_links handles m <= 16");
+    HX_HIP(this, hipSetDevice(device));
+    const uint32_t n_ops = op_off[n_groups], lm0 = 2 * mr.m;
+    size_t o = 0;
+    const size_t o_ctr = o; o += 64;
+    const size_t o_tg = o; o += al16((size_t)n_groups * 4);
+    const size_t o_ly = o; o += al16((size_t)n_groups * 4);
+    const size_t o_off = o; o += al16(((size_t)n_groups + 1) * 4);
+    const size_t o_new = o; o += al16((size_t)n_ops * 4);
+    const size_t o_od = o; o += al16((size_t)n_ops * 4);
+    const size_t in_bytes = o;
+    const size_t o_cnt = o; o += al16((size_t)n_groups * 4);
+    const size_t o_ids = o; o += al16((size_t)n_groups * lm0 * 4);
+    const size_t o_d = o; o += al16((size_t)n_groups * lm0 * 4);
+    if (o > mr.cap_lk) {
+        if (mr.h_lk) (void)hipHostFree(mr.h_lk);
+        if (mr.d_lk) (void)hipFree(mr.d_lk);
+        mr.h_lk = mr.d_lk = nullptr; mr.cap_lk = 0;
+        const size_t n = o * 2;
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_lk, n, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&mr.d_lk, n));
+        mr.cap_lk = n;
+    }
+    uint8_t *h = mr.h_lk;
+    memset(h + o_ctr, 0, 64);
+    memcpy(h + o_tg, target, (size_t)n_groups * 4); memcpy(h + o_ly, layer, (size_t)n_groups * 4);
+    memcpy(h + o_off, op_off, ((size_t)n_groups + 1) * 4);
+    memcpy(h + o_new, op_new, (size_t)n_ops * 4); memcpy(h + o_od, op_d, (size_t)n_ops * 4);
+    HX_HIP(this, hipMemcpyAsync(mr.d_lk, h, in_bytes, hipMemcpyHostToDevice, stream));
+    LinksParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.m = mr.m;
+    p.l0_ids = mr.d_l0_ids; p.l0_d = mr.d_l0_d; p.l0_cnt = mr.d_l0_cnt; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_d = mr.d_up_d; p.up_cnt = mr.d_up_cnt;
+    p.n_groups = n_groups; p.target = (const uint32_t *)(mr.d_lk + o_tg); p.layer = (const uint32_t *)(mr.d_lk + o_ly);
+    p.op_off = (const uint32_t *)(mr.d_lk + o_off); p.op_new = (const uint32_t *)(mr.d_lk + o_new); p.op_d = (const float *)(mr.d_lk + o_od);
+    p.out_ids = (uint32_t *)(mr.d_lk + o_ids); p.out_d = (float *)(mr.d_lk + o_d); p.out_cnt = (uint32_t *)(mr.d_lk + o_cnt);
+    p.n_pairs = (unsigned long long *)(mr.d_lk + o_ctr);
+    { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_links<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_links<OpF16<K>>(this, p)
+    HX_DISPATCH(this, F32C, F16C, ls = launch_links<OpHamming>(this, p), ls = launch_links<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+    HX_HIP(this, ls);
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(h + o_ctr, mr.d_lk + o_ctr, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(h + o_cnt, mr.d_lk + o_cnt, o - o_cnt, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    memcpy(out_cnt, h + o_cnt, (size_t)n_groups * 4);
+    memcpy(out_ids, h + o_ids, (size_t)n_groups * lm0 * 4);
+    memcpy(out_d, h + o_d, (size_t)n_groups * lm0 * 4);
+    unsigned long long np; memcpy(&np, h + o_ctr, 8);
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
     return HX_OK;
 }
 

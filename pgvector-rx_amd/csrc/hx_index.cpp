@@ -561,15 +561,18 @@ struct hx_index {
     std::vector<std::pair<uint32_t, int>> dirty;               // (element, layer) lists the device mirror has not seen yet
     uint32_t mirror_elems = 0;
     uint64_t fused_tasks = 0, fused_redo = 0;
-    double prof[8] = {0};   // seconds: [0] advance, [1] compact, [2] fill, [3] dist launch+wait, [4] pair launch+wait, [5] rounds
+    double prof[16] = {0};   // seconds: [0] advance, [1] compact, [2] fill, [3] dist launch+wait, [4] pair launch+wait, [5] rounds
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
 
     bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192; }
     void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
     // brings the device copy of the graph up to date: levels of new elements + every list written since the last sync
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    struct Timer { double &acc; double t0; explicit Timer(double &a) : acc(a), t0(now_s()) {} ~Timer() { acc += now_s() - t0; } };
     int sync_mirror()
     {
+        Timer tm(prof[7]);
         const uint32_t m = (uint32_t)g.m;
         int rc = e->mirror_reserve(m, g.size(), g.up.size() / m + 1);
         if (rc) return fail(rc, e->err);
@@ -579,7 +582,7 @@ struct hx_index {
         if (n_new == 0 && n_rec == 0) return HX_OK;
         std::vector<int32_t> lv(n_new); std::vector<uint32_t> blk(n_new);
         for (uint32_t i = 0; i < n_new; i++) { lv[i] = g.level[mirror_elems + i]; blk[i] = (uint32_t)(g.up_off[mirror_elems + i] / m); }
-        std::vector<uint32_t> hdr((size_t)n_rec * 4), ids((size_t)n_rec * 2 * m, 0u);
+        std::vector<uint32_t> hdr((size_t)n_rec * 4), ids((size_t)n_rec * 2 * m, 0u); std::vector<float> dd((size_t)n_rec * 2 * m, 0.0f);
         pool->parallel_for((n_rec + 1023) / 1024, [&](size_t ci) {
             for (size_t r = ci * 1024; r < std::min<size_t>(n_rec, ci * 1024 + 1024); r++) {
                 const uint32_t el = dirty[r].first; const int layer = dirty[r].second;
@@ -587,10 +590,10 @@ struct hx_index {
                 const uint16_t c = live ? g.cnt(el, layer) : 0; const Cand *l = live ? g.list(el, layer) : nullptr;
                 hdr[4 * r] = el; hdr[4 * r + 1] = (uint32_t)layer; hdr[4 * r + 2] = c;
                 hdr[4 * r + 3] = layer > 0 ? (uint32_t)(g.up_off[el] / m) + (uint32_t)(layer - 1) : 0u;
-                for (uint16_t k = 0; k < c; k++) ids[r * 2 * m + k] = l[k].id;
+                for (uint16_t k = 0; k < c; k++) { ids[r * 2 * m + k] = l[k].id; dd[r * 2 * m + k] = l[k].d; }
             }
         });
-        if ((rc = e->mirror_update(mirror_elems, n_new, lv.data(), blk.data(), n_rec, hdr.data(), ids.data()))) return fail(rc, e->err);
+        if ((rc = e->mirror_update(mirror_elems, n_new, lv.data(), blk.data(), n_rec, hdr.data(), ids.data(), dd.data()))) return fail(rc, e->err);
         mirror_elems = g.size(); dirty.clear();
         return HX_OK;
     }
@@ -728,6 +731,7 @@ int hx_index_set_threads(hx_index *ix, int n_threads)
 int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids)
 {
     if (!ix) return HX_E_ARG;
+    hx_index::Timer t_bb(ix->prof[12]);
     if (b == 0 || !levels || !tids) return ix->fail(HX_E_ARG, "empty batch or NULL argument");
     Graph &g = ix->g; BatchState &bs = ix->bs;
     if (bs.open) return ix->fail(HX_E_STATE, "a batch is already open");
@@ -746,6 +750,7 @@ int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int
 int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
 {
     if (!ix) return HX_E_ARG;
+    hx_index::Timer t_bs(ix->prof[11]);
     BatchState &bs = ix->bs; Graph &g = ix->g;
     if (!bs.open || lo > hi || hi > bs.b) return ix->fail(HX_E_STATE, "no open batch / bad member range");
     std::vector<uint32_t> todo;                                  // batch members still to be searched by the lock-step path
@@ -856,6 +861,7 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
     for (uint32_t i = 0; i < bs.b; i++) if (!bs.searched[i]) return ix->fail(HX_E_STATE, "batch member without neighbour lists (search or import it first)");
     const uint32_t b = bs.b, base = bs.base;
     int rc;
+    double t_links0 = hx_index::now_s();
     // duplicate detection (build.rs:482-512): byte-compare the leading zero-distance layer-0 neighbours
     std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0);
     for (uint32_t i = 0; i < b; i++) {
@@ -894,6 +900,35 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         bs.grp.push_back({s, t});
         s = t;
     }
+    if (ix->fused_ok() && g.lm(0) + 1 <= 33) {
+        // device path: k_links applies every owned list's back-links (append / prune) in one launch
+        if ((rc = ix->sync_mirror())) return rc;
+        std::vector<uint32_t> tg, ly, off(1, 0u), onew; std::vector<float> od;
+        for (const auto &gr : bs.grp) {
+            if (ops[gr.first].target % world != rank) continue;
+            tg.push_back(ops[gr.first].target); ly.push_back((uint32_t)ops[gr.first].layer);
+            for (size_t k = gr.first; k < gr.second; k++) { onew.push_back(ops[k].new_id); od.push_back(ops[k].d); }
+            off.push_back((uint32_t)onew.size());
+        }
+        const uint32_t ng = (uint32_t)tg.size(), lm0 = 2u * (uint32_t)g.m;
+        ix->prof[8] += hx_index::now_s() - t_links0;
+        if (ng) {
+            hx_index::Timer tl(ix->prof[9]);
+            std::vector<uint32_t> oids((size_t)ng * lm0), ocnt(ng); std::vector<float> odd((size_t)ng * lm0);
+            uint64_t np = 0;
+            if ((rc = ix->e->links_run(ng, tg.data(), ly.data(), off.data(), onew.data(), od.data(), oids.data(), odd.data(), ocnt.data(), &np))) return ix->fail(rc, ix->e->err);
+            ix->counters[3] += np;
+            ix->pool->parallel_for((ng + 2047) / 2048, [&](size_t ci) {
+                for (size_t gi = ci * 2048; gi < std::min<size_t>(ng, ci * 2048 + 2048); gi++) {
+                    Cand *lst = g.list(tg[gi], (int)ly[gi]); const uint32_t c = ocnt[gi];
+                    for (uint32_t k = 0; k < c; k++) lst[k] = Cand{odd[gi * lm0 + k], oids[gi * lm0 + k]};
+                    g.cnt(tg[gi], (int)ly[gi]) = (uint16_t)c;
+                }
+            });
+        }
+        bs.linked = true;
+        return HX_OK;
+    }
     std::vector<std::unique_ptr<BacklinkTask>> &bts = ix->backlink_pool; std::vector<LsTask *> btasks;
     size_t nbt = 0;
     for (const auto &gr : bs.grp) {
@@ -904,7 +939,8 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         bt.g = &g; bt.target = ops[gr.first].target; bt.layer = ops[gr.first].layer; bt.ops.assign(ops.begin() + gr.first, ops.begin() + gr.second);
         btasks.push_back(&bt);
     }
-    if ((rc = ix->run_lockstep(btasks))) return rc;
+    ix->prof[8] += hx_index::now_s() - t_links0;      // duplicates + op grouping + task setup
+    { hx_index::Timer tl(ix->prof[9]); if ((rc = ix->run_lockstep(btasks))) return rc; }
     for (size_t i = 0; i < nbt; i++) { ix->counters[3] += bts[i]->n_pair; ix->dirty.emplace_back(bts[i]->target, bts[i]->layer); }
     bs.linked = true;
     return HX_OK;
@@ -948,6 +984,7 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
 {
     if (!ix) return HX_E_ARG;
     if (n == 0) return HX_OK;
+    hx_index::Timer t_all(ix->prof[10]);
     if (!levels || !tids) return ix->fail(HX_E_ARG, "NULL argument");
     Graph &g = ix->g;
     if (ix->bs.open) return ix->fail(HX_E_STATE, "a staged batch is open");
@@ -1045,7 +1082,7 @@ int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone)
     return HX_OK;
 }
 
-int hx_index_profile(const hx_index *ix, double seconds_out[8], int reset)
+int hx_index_profile(const hx_index *ix, double seconds_out[16], int reset)
 {
     if (!ix || !seconds_out) return HX_E_ARG;
     memcpy(seconds_out, ix->prof, sizeof ix->prof);

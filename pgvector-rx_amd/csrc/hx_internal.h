@@ -40,8 +40,9 @@ struct HxKernelStat { uint64_t launches = 0, units = 0; double ms = 0.0; };
 // device copy of the graph (neighbour ids only) + scratch of the fused traversal kernel (hx_fused.inc.h)
 struct HxMirror {
     uint32_t m = 0; uint64_t cap = 0, cap_blocks = 0;
-    uint32_t *d_l0_ids = nullptr; uint16_t *d_l0_cnt = nullptr; int32_t *d_level = nullptr;
-    uint32_t *d_up_block = nullptr, *d_up_ids = nullptr; uint16_t *d_up_cnt = nullptr;
+    uint32_t *d_l0_ids = nullptr; float *d_l0_d = nullptr; uint16_t *d_l0_cnt = nullptr; int32_t *d_level = nullptr;
+    uint32_t *d_up_block = nullptr, *d_up_ids = nullptr; float *d_up_d = nullptr; uint16_t *d_up_cnt = nullptr;
+    uint8_t *h_lk = nullptr, *d_lk = nullptr; size_t cap_lk = 0;
     uint32_t *d_vis = nullptr; uint64_t cap_vis = 0;
     uint8_t *h_stage = nullptr, *d_stage = nullptr; size_t cap_stage = 0;
     uint8_t *h_io = nullptr, *d_io = nullptr; size_t cap_io = 0;
@@ -55,7 +56,7 @@ struct hx_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timing = false; float last_ms = 0.f;
-    HxKernelStat stat_dist, stat_pair, stat_fused;
+    HxKernelStat stat_dist, stat_pair, stat_fused, stat_links;
     HxMirror mirror;
     HxChannel ch;
     std::string err;
@@ -67,7 +68,12 @@ struct hx_engine {
     // device-resident traversal (hx_fused.inc.h)
     int mirror_reserve(uint32_t m, uint64_t n_elems, uint64_t n_blocks);
     int mirror_update(uint32_t first, uint32_t n_new, const int32_t *levels, const uint32_t *blocks,
-                      uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids);
+                      uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids, const float *dists);
+    // update_neighbor_connections on the device for n_groups (target, layer) lists: group g applies ops
+    // [op_off[g], op_off[g+1]) = (new element, its distance to the target) in order; the lists are read from and written
+    // back to the mirror, and returned: out_cnt[g], out_ids/out_d [g][2m]
+    int links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
+                  const uint32_t *op_new, const float *op_d, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint64_t *n_pairs);
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
                   uint64_t counts[2]);
