@@ -368,7 +368,7 @@ class Index:
     def fused_stats(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(lib().hx_index_fused_stats(self.h, C.byref(a), C.byref(b)))
-        return {"tasks": a.value, "redone": b.value}
+        return {"tasks": a.value, "redone": b.value & 0xFFFFFFFF, "max_candidate_heap": b.value >> 32}
 
     def search(self, nq, ef_search, k):
         tids = np.full((nq, k), -1, np.int64)

@@ -17,7 +17,7 @@
 // FS_OVERFLOW and is re-run by the lock-step path (still on the GPU kernels: there is no CPU fallback).
 
 #define FUSED_MAXCH 8          /* 1 KiB chunks per row: pitch <= 8192 B covers vector(2000), halfvec(4000), bit(64000) */
-#define FUSED_RB 4             /* rows in flight per wave */
+#define FUSED_RB 8             /* rows in flight per wave (one 1 KiB chunk of each, double-buffered) */
 #define FUSED_MAXL 8           /* layers 0..7 handled on the device (P(level >= 8) = 16^-8 at m=16) */
 enum { FS_OK = 0, FS_OVERFLOW = 1, FS_HOST = 2 };
 
@@ -31,7 +31,7 @@ struct FusedParams {
     uint32_t *vis; uint64_t vis_words;            // per-workgroup visited bitmap, vis_words 32-bit words each
     uint32_t *next_task;
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
-    unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances
+    unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
 };
 
 struct FHeapItem { float d; uint32_t id; };
@@ -76,49 +76,57 @@ template <bool NEAREST> struct FHeap {
 };
 
 struct FusedCtx {
-    uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL;
+    uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV;
     uint32_t *vis; uint32_t lane; uint32_t status;
-    unsigned long long nd0, nd1;
+    unsigned long long nd0, nd1; uint32_t cmax;
 };
 
-// 16-byte fragments of one vector (row or query slot) into registers; lanes past the pitch hold zeros
-__device__ __forceinline__ void f_load_frags(const FusedParams &p, const uint8_t *src, uint32_t lane, u4 (&f)[FUSED_MAXCH])
+// parks one vector (row or query slot) in LDS, chunk-major: bytes [c*1024 + 16*lane, +16); zero past the pitch
+__device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
 {
-#pragma unroll
-    for (int c = 0; c < FUSED_MAXCH; c++) {
+    for (uint32_t c = 0; c < p.nch; c++) {
         const uint32_t off = c * 1024u + lane * 16u;
         u4 v = {0u, 0u, 0u, 0u};
-        if ((uint32_t)c < p.nch && off < p.pitch) v = *(const u4 *)(src + off);
-        f[c] = v;
+        if (off < p.pitch) v = *(const u4 *)(src + off);
+        *(u4 *)(dst + off) = v;
     }
+    __syncthreads();
 }
 
-// distances from the fragment set f to rows ids[0..n) (LDS); lane j (< 64) returns d(f, ids[j]); n <= 64
+// distances from the vector parked at `qv` (LDS) to rows ids[0..n) (LDS); lane j (< 64) returns d(q, ids[j]); n <= 64.
+// FUSED_RB rows are in flight at a time, one 1 KiB chunk of each; the loads of chunk c+1 are issued before chunk c is
+// consumed.  The chunk loop is a real loop (not unrolled) so register use does not grow with the row length.
 template <class OP>
-__device__ __forceinline__ float f_dist_batch(const FusedParams &p, const u4 (&f)[FUSED_MAXCH], const uint32_t *ids, uint32_t n, uint32_t lane)
+__device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
 {
     float mine = 0.0f;
+    const uint32_t loff = lane * 16u;
     for (uint32_t j0 = 0; j0 < n; j0 += FUSED_RB) {
-        u4 rv[FUSED_RB][FUSED_MAXCH];
+        const uint8_t *rp[FUSED_RB];
 #pragma unroll
-        for (int r = 0; r < FUSED_RB; r++) {
-            const uint32_t j = j0 + r < n ? j0 + r : j0;
-            const uint8_t *rp = p.rows + (size_t)ids[j] * p.pitch;
+        for (int r = 0; r < FUSED_RB; r++) rp[r] = p.rows + (size_t)ids[j0 + r < n ? j0 + r : j0] * p.pitch + loff;
+        typename OP::acc_t acc[FUSED_RB];
 #pragma unroll
-            for (int c = 0; c < FUSED_MAXCH; c++) {
-                const uint32_t off = c * 1024u + lane * 16u;
-                u4 v = {0u, 0u, 0u, 0u};
-                if ((uint32_t)c < p.nch && off < p.pitch) v = *(const u4 *)(rp + off);
-                rv[r][c] = v;
+        for (int r = 0; r < FUSED_RB; r++) OP::init(acc[r]);
+        u4 cur[FUSED_RB], nxt[FUSED_RB];
+#pragma unroll
+        for (int r = 0; r < FUSED_RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (loff < p.pitch) v = *(const u4 *)(rp[r]); cur[r] = v; nxt[r] = v; }
+#pragma unroll 1
+        for (uint32_t c = 0; c < p.nch; c++) {
+            const uint32_t o1 = (c + 1u) * 1024u;
+            if (c + 1u < p.nch) {
+#pragma unroll
+                for (int r = 0; r < FUSED_RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (o1 + loff < p.pitch) v = *(const u4 *)(rp[r] + o1); nxt[r] = v; }
             }
+            const u4 q = *(const u4 *)(qv + c * 1024u + loff);
+#pragma unroll
+            for (int r = 0; r < FUSED_RB; r++) OP::add(acc[r], q, cur[r]);
+#pragma unroll
+            for (int r = 0; r < FUSED_RB; r++) cur[r] = nxt[r];
         }
 #pragma unroll
         for (int r = 0; r < FUSED_RB; r++) {
-            typename OP::acc_t acc; OP::init(acc);
-#pragma unroll
-            for (int c = 0; c < FUSED_MAXCH; c++)
-                if ((uint32_t)c < p.nch) OP::add(acc, f[c], rv[r][c]);
-            const float d = OP::template finish<64>(acc);
+            const float d = OP::template finish<64>(acc[r]);
             if (j0 + r < n && lane == j0 + r) mine = d;
         }
     }
@@ -128,7 +136,7 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const u4 (&f
 // Algorithm 2 with entry points EP[0..n_ep); leaves the result set in the W heap (cx.CTL[1] = |W|).
 // scan == false: search_layer (graph/mod.rs:161-255); scan == true: search_layer_disk without `discarded` (scan.rs:302-448).
 template <class OP>
-__device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, const u4 (&qf)[FUSED_MAXCH], uint32_t n_ep, uint32_t ef, int layer, bool scan)
+__device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan)
 {
     const uint32_t lane = cx.lane;
     // fresh visited set
@@ -184,7 +192,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, const u4 (&qf
             if (cnt == 0) continue;
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
             __syncthreads();
-            const float mine = f_dist_batch<OP>(p, qf, cx.IDS, cnt, lane);
+            const float mine = f_dist_batch<OP>(p, cx.QV, cx.IDS, cnt, lane);
             if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
             cx.nd0 += cnt;
             __syncthreads();
@@ -199,6 +207,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, const u4 (&qf
                     if (!add) continue;
                     if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
                     FHeap<true>::push(cx.C, clen, it); FHeap<false>::push(cx.W, wl, it); rlen++;
+                    if (clen > cx.cmax) cx.cmax = clen;
                     if (rlen > ef) { (void)FHeap<false>::pop(cx.W, wl); rlen--; }
                 }
                 cx.CTL[0] = clen; cx.CTL[1] = wl; cx.CTL[2] = rlen;
@@ -228,23 +237,27 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
 }
 
 template <class OP, int MODE>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors)
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 4)
 k_fused(const FusedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     FusedCtx cx;
     const uint32_t lm0 = 2u * p.m;
+    // LDS carve: C[ccap] | W[ef+2] | EP[ef+2] | RES[64] | RL[2m] | IDS[64] CTL[16] | QV[nch KiB].  The select phase runs
+    // after the layer's search is over, so its scratch (the candidate under test EV and the discarded list DL) reuses C.
     cx.C = (uint2 *)lds;
     cx.W = cx.C + p.ccap;
     cx.EP = cx.W + (p.ef + 2);
     cx.RES = cx.EP + (p.ef + 2);
     cx.RL = cx.RES + 64;
-    cx.DL = cx.RL + lm0;
-    cx.IDS = (uint32_t *)(cx.DL + (p.ef + 2));
+    cx.IDS = (uint32_t *)(cx.RL + lm0);
     cx.CTL = cx.IDS + 64;
+    cx.QV = (uint8_t *)(cx.CTL + 16);                     // query parked in LDS (nch KiB)
+    cx.EV = (uint8_t *)cx.C;                              // host guarantees ccap*8 >= nch*1024 + (ef+2)*8
+    cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
     cx.lane = threadIdx.x;
     cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
-    cx.nd0 = cx.nd1 = 0;
+    cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
     const uint32_t lane = cx.lane;
 
     for (;;) {
@@ -256,15 +269,14 @@ k_fused(const FusedParams p)
         cx.status = FS_OK;
         const uint32_t qsel = p.t_qsel[t];
         const uint8_t *qsrc = (qsel & HX_QUERY_SLOT) ? p.queries + (size_t)(qsel & 0x7fffffffu) * p.pitch : p.rows + (size_t)qsel * p.pitch;
-        u4 qf[FUSED_MAXCH];
-        f_load_frags(p, qsrc, lane, qf);
+        f_park(p, qsrc, lane, cx.QV);
         const int new_level = MODE == 1 ? p.t_level[t] : -1;
         if (MODE == 1 && new_level >= FUSED_MAXL) { if (lane == 0) p.status[t] = FS_HOST; continue; }
 
         // d(q, entry point): mod.rs:371-377 / scan.rs:475
         if (lane == 0) cx.IDS[0] = p.entry;
         __syncthreads();
-        const float d0 = f_dist_batch<OP>(p, qf, cx.IDS, 1, lane);
+        const float d0 = f_dist_batch<OP>(p, cx.QV, cx.IDS, 1, lane);
         cx.nd0 += 1;
         if (lane == 0) cx.EP[0] = fh_pack(d0, p.entry);
         __syncthreads();
@@ -273,7 +285,7 @@ k_fused(const FusedParams p)
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
         const int stop_above = MODE == 1 ? new_level : 0;
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
-            f_search_layer<OP>(p, cx, qf, n_ep, 1u, lc, MODE == 0);
+            f_search_layer<OP>(p, cx, n_ep, 1u, lc, MODE == 0);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
                 f_sort_results(cx, wl, MODE == 0);
@@ -285,7 +297,7 @@ k_fused(const FusedParams p)
         if (MODE == 0) {
             uint32_t cnt = 0;
             if (cx.status == FS_OK && n_ep > 0) {
-                f_search_layer<OP>(p, cx, qf, n_ep, p.ef, 0, true);                  // scan.rs:515-528
+                f_search_layer<OP>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, true);                                        // nearest LAST
                 cnt = wl < p.k ? wl : p.k;
@@ -301,7 +313,7 @@ k_fused(const FusedParams p)
             for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
             for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
                 const uint32_t lm = lc == 0 ? lm0 : p.m;
-                f_search_layer<OP>(p, cx, qf, n_ep, p.ef, lc, false);                // mod.rs:407-416
+                f_search_layer<OP>(p, cx, n_ep, p.ef, lc, false);                // mod.rs:407-416
                 if (cx.status != FS_OK) break;
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
@@ -317,11 +329,9 @@ k_fused(const FusedParams p)
                         const uint2 e = cx.EP[i];
                         bool closer = true;                                          // check_element_closer, mod.rs:315-339
                         if (r > 0) {
-                            u4 ef_[FUSED_MAXCH];
-                            f_load_frags(p, p.rows + (size_t)e.y * p.pitch, lane, ef_);
                             if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
-                            __syncthreads();
-                            const float dj = f_dist_batch<OP>(p, ef_, cx.IDS, r, lane);
+                            f_park(p, p.rows + (size_t)e.y * p.pitch, lane, cx.EV);
+                            const float dj = f_dist_batch<OP>(p, cx.EV, cx.IDS, r, lane);
                             cx.nd1 += r;
                             closer = __ballot(lane < r && dj <= fh_d(e)) == 0ull;    // mod.rs:333-335 (any r rejects)
                             __syncthreads();
@@ -344,7 +354,7 @@ k_fused(const FusedParams p)
         }
         __syncthreads();
     }
-    if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); }
+    if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax); }
 }
 
 // ---- device graph mirror maintenance ------------------------------------------------------------------------
@@ -625,7 +635,7 @@ static hipError_t launch_links(hx_engine *e, const LinksParams &p)
 }
 
 int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
-                         const uint32_t *op_new, const float *op_d, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint64_t *n_pairs)
+                         const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs)
 {
     HxMirror &mr = mirror;
     if (n_groups == 0) return HX_OK;
@@ -678,9 +688,7 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     HX_HIP(this, hipMemcpyAsync(h + o_ctr, mr.d_lk + o_ctr, 64, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipMemcpyAsync(h + o_cnt, mr.d_lk + o_cnt, o - o_cnt, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
-    memcpy(out_cnt, h + o_cnt, (size_t)n_groups * 4);
-    memcpy(out_ids, h + o_ids, (size_t)n_groups * lm0 * 4);
-    memcpy(out_d, h + o_d, (size_t)n_groups * lm0 * 4);
+    *out_cnt = (const uint32_t *)(h + o_cnt); *out_ids = (const uint32_t *)(h + o_ids); *out_d = (const float *)(h + o_d);
     unsigned long long np; memcpy(&np, h + o_ctr, 8);
     if (n_pairs) *n_pairs = np;
     if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
@@ -718,9 +726,12 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
     HX_HIP(this, hipSetDevice(device));
     // LDS: C[ccap] W[ef+2] EP[ef+2] RES[64] RL[2m] DL[ef+2] (8 B each) + IDS[64] + CTL[16] (4 B each)
-    uint32_t ccap = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, ef * 12u));
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 3 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16) * 4; };
-    while (lds_bytes(ccap) > 60 * 1024 && ccap > 512) ccap -= 256;
+    // candidate-heap budget: 9*ef entries covered the largest heap seen on 1M x 768 builds (1552 at ef = 200); a task that
+    // needs more reports FS_OVERFLOW and is re-run by the lock-step path
+    const size_t nch_ = (pitch + 1023) / 1024;
+    uint32_t ccap = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, ef * 9u));
+    ccap = std::max<uint32_t>(ccap, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16) * 4 + nch_ * 1024; };
     const size_t lds = lds_bytes(ccap);
     // residency: one wave per workgroup, LDS-limited
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
@@ -786,8 +797,9 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
     memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
     memcpy(out_d, mr.h_io + o_d, out_n * 4);
-    unsigned long long nd[2]; memcpy(nd, mr.h_io + o_ctr + 16, 16);
+    unsigned long long nd[3]; memcpy(nd, mr.h_io + o_ctr + 16, 24);
     if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }
+    if (nd[2] > fused_cmax) fused_cmax = nd[2];
     if (timing) {
         float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev0, ev1));
         last_ms = ms; stat_fused.launches++; stat_fused.units += nd[0] + nd[1]; stat_fused.ms += ms;

@@ -872,51 +872,92 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
     std::vector<uint8_t> deq(da.size());
     if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
     std::vector<BackOp> &ops = bs.ops; ops.clear();
+    std::vector<uint32_t> opstart(b + 1, 0);                    // ops of member i land at [opstart[i], opstart[i+1])
     for (uint32_t i = 0; i < b; i++) {
         const uint32_t id = base + i;
         int64_t dup = -1;
         for (uint32_t k = dstart[i]; k < dstart[i + 1]; k++)
             if (deq[k] && g.ntids[db[k]] < HEAPTIDS && g.level[db[k]] >= 0) { dup = db[k]; break; }
+        uint32_t nops = 0;
         if (dup >= 0) {                                     // merge into the existing element; this row becomes a tombstone
             g.tids[dup][g.ntids[dup]++] = bs.tids[i];
             for (int lc = 0; lc <= g.level[id]; lc++) g.cnt(id, lc) = 0;
             g.level[id] = -1 - g.level[id];
             bs.elem[i] = (uint32_t)dup;
-            continue;
+        } else {
+            for (int lc = g.level[id]; lc >= 0; lc--) nops += g.cnt(id, lc);
+            if (g.level[id] > g.level[g.entry]) g.entry = id;   // build.rs:523-525
+            g.tids[id][0] = bs.tids[i]; g.ntids[id] = 1;
+            bs.elem[i] = id;
         }
-        for (int lc = g.level[id]; lc >= 0; lc--) {         // update_neighbor_connections order (mod.rs:451-458)
-            const Cand *lst = g.list(id, lc);
-            for (uint16_t k = 0; k < g.cnt(id, lc); k++) ops.push_back(BackOp{lst[k].id, lc, id, lst[k].d});
-        }
-        if (g.level[id] > g.level[g.entry]) g.entry = id;   // build.rs:523-525
-        g.tids[id][0] = bs.tids[i]; g.ntids[id] = 1;
-        bs.elem[i] = id;
+        opstart[i + 1] = opstart[i] + nops;
     }
-    // group back-links per (target, layer), keeping insertion order inside a group
-    std::stable_sort(ops.begin(), ops.end(), [](const BackOp &a, const BackOp &c) { return a.target != c.target ? a.target < c.target : a.layer < c.layer; });
-    bs.grp.clear();
-    for (size_t s = 0; s < ops.size();) {
-        size_t t = s; while (t < ops.size() && ops[t].target == ops[s].target && ops[t].layer == ops[s].layer) t++;
-        bs.grp.push_back({s, t});
-        s = t;
+    // Back-link ops in update_neighbor_connections order (mod.rs:451-458), then grouped per (target, layer) with the
+    // insertion order kept inside a group: parallel stable bucket sort (bucket = target & 255; buckets are independent).
+    {
+        const uint32_t n_ops = opstart[b];
+        constexpr uint32_t NB = 256;
+        const uint32_t csz = 128, nck = (b + csz - 1) / csz;
+        std::vector<BackOp> raw(n_ops);
+        std::vector<uint32_t> hist((size_t)nck * NB, 0u);
+        ix->pool->parallel_for(nck, [&](size_t ci) {
+            uint32_t *h = &hist[ci * NB];
+            for (uint32_t i = (uint32_t)ci * csz; i < std::min(b, (uint32_t)(ci + 1) * csz); i++) {
+                const uint32_t id = base + i; uint32_t o = opstart[i];
+                if (opstart[i + 1] == o) continue;
+                for (int lc = g.level[id]; lc >= 0; lc--) {
+                    const Cand *lst = g.list(id, lc);
+                    for (uint16_t k = 0; k < g.cnt(id, lc); k++) { raw[o++] = BackOp{lst[k].id, lc, id, lst[k].d}; h[lst[k].id & (NB - 1)]++; }
+                }
+            }
+        });
+        std::vector<uint32_t> bstart(NB + 1, 0u);
+        for (uint32_t bk = 0; bk < NB; bk++) { uint32_t t = 0; for (uint32_t c = 0; c < nck; c++) t += hist[(size_t)c * NB + bk]; bstart[bk + 1] = bstart[bk] + t; }
+        // per (chunk, bucket) write cursor = bucket start + ops of earlier chunks in that bucket (keeps insertion order)
+        for (uint32_t bk = 0; bk < NB; bk++) { uint32_t run = bstart[bk]; for (uint32_t c = 0; c < nck; c++) { const uint32_t t = hist[(size_t)c * NB + bk]; hist[(size_t)c * NB + bk] = run; run += t; } }
+        ops.resize(n_ops);
+        ix->pool->parallel_for(nck, [&](size_t ci) {
+            uint32_t *cur = &hist[ci * NB];
+            const uint32_t lo = opstart[std::min<size_t>(b, ci * csz)], hi = opstart[std::min<size_t>(b, (ci + 1) * csz)];
+            for (uint32_t o = lo; o < hi; o++) ops[cur[raw[o].target & (NB - 1)]++] = raw[o];
+        });
+        std::vector<std::vector<std::pair<size_t, size_t>>> bgrp(NB);
+        ix->pool->parallel_for(NB, [&](size_t bk) {
+            std::stable_sort(ops.begin() + bstart[bk], ops.begin() + bstart[bk + 1],
+                             [](const BackOp &a, const BackOp &c) { return a.target != c.target ? a.target < c.target : a.layer < c.layer; });
+            for (size_t s0 = bstart[bk]; s0 < bstart[bk + 1];) {
+                size_t t = s0; while (t < bstart[bk + 1] && ops[t].target == ops[s0].target && ops[t].layer == ops[s0].layer) t++;
+                bgrp[bk].push_back({s0, t});
+                s0 = t;
+            }
+        });
+        bs.grp.clear();
+        for (uint32_t bk = 0; bk < NB; bk++) bs.grp.insert(bs.grp.end(), bgrp[bk].begin(), bgrp[bk].end());
     }
     if (ix->fused_ok() && g.lm(0) + 1 <= 33) {
         // device path: k_links applies every owned list's back-links (append / prune) in one launch
         if ((rc = ix->sync_mirror())) return rc;
-        std::vector<uint32_t> tg, ly, off(1, 0u), onew; std::vector<float> od;
-        for (const auto &gr : bs.grp) {
-            if (ops[gr.first].target % world != rank) continue;
-            tg.push_back(ops[gr.first].target); ly.push_back((uint32_t)ops[gr.first].layer);
-            for (size_t k = gr.first; k < gr.second; k++) { onew.push_back(ops[k].new_id); od.push_back(ops[k].d); }
-            off.push_back((uint32_t)onew.size());
-        }
-        const uint32_t ng = (uint32_t)tg.size(), lm0 = 2u * (uint32_t)g.m;
+        std::vector<uint32_t> own;                               // indices into bs.grp of the lists this rank owns
+        own.reserve(bs.grp.size());
+        for (uint32_t gi = 0; gi < bs.grp.size(); gi++) if (ops[bs.grp[gi].first].target % world == rank) own.push_back(gi);
+        const uint32_t ng = (uint32_t)own.size(), lm0 = 2u * (uint32_t)g.m;
+        std::vector<uint32_t> tg(ng), ly(ng), off(ng + 1, 0u);
+        for (uint32_t k = 0; k < ng; k++) off[k + 1] = off[k] + (uint32_t)(bs.grp[own[k]].second - bs.grp[own[k]].first);
+        std::vector<uint32_t> onew(off[ng]); std::vector<float> od(off[ng]);
+        ix->pool->parallel_for((ng + 4095) / 4096, [&](size_t ci) {
+            for (size_t k = ci * 4096; k < std::min<size_t>(ng, ci * 4096 + 4096); k++) {
+                const auto &gr = bs.grp[own[k]];
+                tg[k] = ops[gr.first].target; ly[k] = (uint32_t)ops[gr.first].layer;
+                uint32_t o = off[k];
+                for (size_t q = gr.first; q < gr.second; q++) { onew[o] = ops[q].new_id; od[o] = ops[q].d; o++; }
+            }
+        });
         ix->prof[8] += hx_index::now_s() - t_links0;
         if (ng) {
             hx_index::Timer tl(ix->prof[9]);
-            std::vector<uint32_t> oids((size_t)ng * lm0), ocnt(ng); std::vector<float> odd((size_t)ng * lm0);
+            const uint32_t *oids = nullptr, *ocnt = nullptr; const float *odd = nullptr;
             uint64_t np = 0;
-            if ((rc = ix->e->links_run(ng, tg.data(), ly.data(), off.data(), onew.data(), od.data(), oids.data(), odd.data(), ocnt.data(), &np))) return ix->fail(rc, ix->e->err);
+            if ((rc = ix->e->links_run(ng, tg.data(), ly.data(), off.data(), onew.data(), od.data(), &oids, &odd, &ocnt, &np))) return ix->fail(rc, ix->e->err);
             ix->counters[3] += np;
             ix->pool->parallel_for((ng + 2047) / 2048, [&](size_t ci) {
                 for (size_t gi = ci * 2048; gi < std::min<size_t>(ng, ci * 2048 + 2048); gi++) {
@@ -1078,7 +1119,7 @@ int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone)
 {
     if (!ix) return HX_E_ARG;
     if (tasks) *tasks = ix->fused_tasks;
-    if (redone) *redone = ix->fused_redo;
+    if (redone) *redone = ix->fused_redo | (ix->e->fused_cmax << 32);   // high half: max candidate-heap length seen (diagnostic)
     return HX_OK;
 }
 

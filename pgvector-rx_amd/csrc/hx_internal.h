@@ -58,6 +58,7 @@ struct hx_engine {
     bool timing = false; float last_ms = 0.f;
     HxKernelStat stat_dist, stat_pair, stat_fused, stat_links;
     HxMirror mirror;
+    uint64_t fused_cmax = 0;      // largest candidate-heap length any fused task reached (sizing the LDS budget)
     HxChannel ch;
     std::string err;
 
@@ -73,7 +74,7 @@ struct hx_engine {
     // [op_off[g], op_off[g+1]) = (new element, its distance to the target) in order; the lists are read from and written
     // back to the mirror, and returned: out_cnt[g], out_ids/out_d [g][2m]
     int links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
-                  const uint32_t *op_new, const float *op_d, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint64_t *n_pairs);
+                  const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs);
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
                   uint64_t counts[2]);
