@@ -189,15 +189,30 @@ def main():
                     "frac": round(f_gbps / HBM_PEAK_GBPS, 4), "traffic": None, "launches": fstat["launches"],
                     "avg_launch_ms": round(f_ms, 3), "distances_per_launch": round(fstat["units"] / fstat["launches"], 1),
                     "bytes_per_distance": row_bytes}
+        # every launch of this kernel in the process (warmup + timed): what `rocprofv3 --kernel-trace --stats` averages
+        al, ams = warm_fused["launches"] + fstat["launches"], warm_fused["ms"] + fstat["ms"]
+        roofline["whole_run"] = {"launches": al, "avg_launch_ms": round(ams / max(1, al), 3),
+                                 "achieved": round((warm_fused["units"] + fstat["units"]) * row_bytes / max(ams, 1e-9) / 1e6, 1)}
+        # HBM traffic per launch from a separate `rocprofv3 --pmc FETCH_SIZE` pass of this same command (profiles/), if recorded
+        pmc = os.path.join(ROOT, "profiles", "pmc_k_fused_query.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("rows") == a.rows and rec.get("dim") == a.dim and rec.get("queries") == a.queries and rec.get("efs") == a.efs:
+                    roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = rec.get("source")
+            except Exception:
+                pass
     bd, bp = build_stats["dist"], build_stats["pair"]
     bf = build_stats["fused"]
     bl = build_stats["links"]
     # every K1 launch of this process (build + warmup + timed steps): the figure a `rocprofv3 --kernel-trace --stats`
     # run of this same command reports as the kernel's average duration
-    all_l = bd["launches"] + warm_stat["launches"] + sstat["launches"]
-    all_ms = bd["ms"] + warm_stat["ms"] + sstat["ms"]
-    roofline["whole_run"] = {"launches": all_l, "avg_launch_us": round(1000.0 * all_ms / max(1, all_l), 2),
-                             "achieved": round((bd["units"] + warm_stat["units"] + sstat["units"]) * row_bytes / max(all_ms, 1e-9) / 1e6, 1)}
+    if not fstat["launches"]:
+        all_l = bd["launches"] + warm_stat["launches"] + sstat["launches"]
+        all_ms = bd["ms"] + warm_stat["ms"] + sstat["ms"]
+        roofline["whole_run"] = {"launches": all_l, "avg_launch_us": round(1000.0 * all_ms / max(1, all_l), 2),
+                                 "achieved": round((bd["units"] + warm_stat["units"] + sstat["units"]) * row_bytes / max(all_ms, 1e-9) / 1e6, 1)}
     build_kernels = {
         "k_dist_groups": {"launches": bd["launches"], "distances": bd["units"], "ms": round(bd["ms"], 1),
                           "GBps": round(bd["units"] * row_bytes / max(bd["ms"], 1e-9) / 1e6, 1)},

@@ -283,3 +283,64 @@ def test_reference_recall_gate_on_device(gate):
         assert correct / (k * len(qs)) >= min_recall, (metric, correct / (k * len(qs)))
         ix.close()
         e.close()
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "lockstep"])
+def test_staged_batches_two_rank_simulation(fused):
+    """The multi-GPU protocol of pgvector-rx_amd/dist_build.py, played by two engines on one GPU: each 'rank' searches
+    its slice and prunes the lists it owns, the serialized lists are exchanged by hand, and both replicas must end up
+    bit-identical to the single-rank build (and hence to the oracle)."""
+    import importlib
+    db = importlib.import_module("pgvector-rx_amd.dist_build")
+    rng = np.random.default_rng(77)
+    n, dim, m, efc, batch, world = 1500, 24, 8, 32, 96, 2
+    rows = make_rows(hx.F32, n, dim, rng)
+    rows[300] = rows[5]
+    levels = hx.draw_levels(n, m, seed=3)
+    tids = np.arange(n, dtype=np.int64)
+    e0, ix0, _, o, _ = build_both(hx.F32, hx.L2SQ, dim, rows, levels, m, efc, batch, fused)
+    ranks = []
+    for r in range(world):
+        e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+        e.append(rows)
+        ix = hx.Index(e, m, efc)
+        ix.set_fused(fused)
+        ranks.append((e, ix))
+    done = 0
+    for b in hx.batch_schedule(0, n, batch):
+        if ranks[0][1].entry < 0 or b < 16:
+            for _, ix in ranks:
+                ix.insert(done, levels[done:done + b], tids[done:done + b], batch=b)
+            done += b
+            continue
+        lo, hi = db.slice_bounds(b, world)
+        for r, (_, ix) in enumerate(ranks):
+            ix.batch_begin(done, levels[done:done + b], tids[done:done + b])
+            ix.batch_search(lo[r], hi[r])
+        bufs = [ix.batch_export_new(lo[r], hi[r]) for r, (_, ix) in enumerate(ranks)]
+        for r, (_, ix) in enumerate(ranks):
+            for s in range(world):
+                if s != r and hi[s] > lo[s]:
+                    ix.batch_import_new(lo[s], hi[s], bufs[s])
+        for r, (_, ix) in enumerate(ranks):
+            ix.batch_links(r, world)
+        bufs = [ix.batch_export_links(r, world) for r, (_, ix) in enumerate(ranks)]
+        for r, (_, ix) in enumerate(ranks):
+            for s in range(world):
+                if s != r and len(bufs[s]):
+                    ix.batch_import_links(s, world, bufs[s])
+            ix.batch_end(b)
+        done += b
+    for _, ix in ranks:
+        assert_same_graph(ix, o, n)
+    # a search on a replica that imported half of its lists (mirror refreshed from imports)
+    qs = make_rows(hx.F32, 16, dim, rng)
+    for e, ix in ranks + [(e0, ix0)]:
+        e.set_queries(qs)
+    ref = ix0.search(16, 40, 10)
+    for _, ix in ranks:
+        got = ix.search(16, 40, 10)
+        assert (got[0] == ref[0]).all() and (got[1].view(np.uint32) == ref[1].view(np.uint32)).all()
+    for e, ix in ranks + [(e0, ix0)]:
+        ix.close()
+        e.close()
