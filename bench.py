@@ -47,6 +47,9 @@ def parse():
     p.add_argument("--cpu-queries", type=int, default=300)
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-fused", action="store_true", help="run every traversal in the lock-step host driver")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo = rehearsal of the multi-rank build with CPU-side exchange (several ranks may share one GPU)")
+    p.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     return p.parse_args()
 
 
@@ -96,11 +99,17 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     import torch.distributed as dist
+    if a.share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if a.dist_backend == "nccl" else torch.device("cpu")     # where collectives' tensors live
 
     def barrier():
         if world > 1:
@@ -126,13 +135,13 @@ def main():
     t0 = time.perf_counter()
     if world > 1:
         from importlib import import_module
-        import_module("pgvector-rx_amd.dist_build").insert_sharded(ix, 0, levels, a.batch, dist, dev)
+        import_module("pgvector-rx_amd.dist_build").insert_sharded(ix, 0, levels, a.batch, dist, xdev)
     else:
         ix.insert(0, levels, batch=a.batch)
     barrier()
     build_sec = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([build_sec], device=dev, dtype=torch.float64)
+        t = torch.tensor([build_sec], device=xdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         build_sec = float(t.item())
     build_stats = {"dist": eng.kernel_stats(0, reset=True), "pair": eng.kernel_stats(1, reset=True), "fused": eng.kernel_stats(2, reset=True), "links": eng.kernel_stats(3, reset=True)}
@@ -152,7 +161,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=xdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     sstat = eng.kernel_stats(0)
@@ -163,7 +172,7 @@ def main():
     gt = ground_truth(rows, queries, a.k)
     recall = recall_at_k(tids, cnt, gt, a.k)
     if world > 1:
-        t = torch.tensor([recall], device=dev, dtype=torch.float64)
+        t = torch.tensor([recall], device=xdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         recall = float(t.item()) / world
 

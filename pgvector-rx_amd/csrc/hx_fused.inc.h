@@ -16,8 +16,10 @@
 // tests compare the two paths and the oracle.  A task whose candidate heap would overflow its LDS budget reports
 // FS_OVERFLOW and is re-run by the lock-step path (still on the GPU kernels: there is no CPU fallback).
 
+#include <cstdio>
 #define FUSED_MAXCH 8          /* 1 KiB chunks per row: pitch <= 8192 B covers vector(2000), halfvec(4000), bit(64000) */
-#define FUSED_RB 8             /* rows in flight per wave (one 1 KiB chunk of each, double-buffered) */
+#define FUSED_RB 4             /* rows in flight per wave ... */
+#define FUSED_CG 3             /* ... times chunks of each requested at once */
 #define FUSED_MAXL 8           /* layers 0..7 handled on the device (P(level >= 8) = 16^-8 at m=16) */
 enum { FS_OK = 0, FS_OVERFLOW = 1, FS_HOST = 2 };
 
@@ -32,6 +34,7 @@ struct FusedParams {
     uint32_t *next_task;
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
+    uint32_t fdbg;                                // experiments (HX_F_DBG): 1 no pre-filter, 4 phase timers into n_dist[3..7]
 };
 
 struct FHeapItem { float d; uint32_t id; };
@@ -79,6 +82,7 @@ struct FusedCtx {
     uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV;
     uint32_t *vis; uint32_t lane; uint32_t status;
     unsigned long long nd0, nd1; uint32_t cmax;
+    unsigned long long tph[5];   // diagnostic phase clocks (HX_F_DBG & 4): pop, list+visited, distances, replay, other
 };
 
 // parks one vector (row or query slot) in LDS, chunk-major: bytes [c*1024 + 16*lane, +16); zero past the pitch
@@ -94,8 +98,8 @@ __device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src,
 }
 
 // distances from the vector parked at `qv` (LDS) to rows ids[0..n) (LDS); lane j (< 64) returns d(q, ids[j]); n <= 64.
-// FUSED_RB rows are in flight at a time, one 1 KiB chunk of each; the loads of chunk c+1 are issued before chunk c is
-// consumed.  The chunk loop is a real loop (not unrolled) so register use does not grow with the row length.
+// FUSED_RB rows x FUSED_CG 1-KiB chunks are requested at once (one HBM latency per row batch at d <= 768 f32), then
+// consumed chunk by chunk in ascending order -- the canonical per-lane order.
 template <class OP>
 __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
 {
@@ -108,21 +112,24 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
         typename OP::acc_t acc[FUSED_RB];
 #pragma unroll
         for (int r = 0; r < FUSED_RB; r++) OP::init(acc[r]);
-        u4 cur[FUSED_RB], nxt[FUSED_RB];
-#pragma unroll
-        for (int r = 0; r < FUSED_RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (loff < p.pitch) v = *(const u4 *)(rp[r]); cur[r] = v; nxt[r] = v; }
 #pragma unroll 1
-        for (uint32_t c = 0; c < p.nch; c++) {
-            const uint32_t o1 = (c + 1u) * 1024u;
-            if (c + 1u < p.nch) {
+        for (uint32_t c0 = 0; c0 < p.nch; c0 += FUSED_CG) {
+            u4 rv[FUSED_RB][FUSED_CG];
 #pragma unroll
-                for (int r = 0; r < FUSED_RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (o1 + loff < p.pitch) v = *(const u4 *)(rp[r] + o1); nxt[r] = v; }
+            for (int k = 0; k < FUSED_CG; k++) {
+                const uint32_t off = (c0 + k) * 1024u;
+                const bool in = c0 + k < p.nch && off + loff < p.pitch;
+#pragma unroll
+                for (int r = 0; r < FUSED_RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (in) v = *(const u4 *)(rp[r] + off); rv[r][k] = v; }
             }
-            const u4 q = *(const u4 *)(qv + c * 1024u + loff);
 #pragma unroll
-            for (int r = 0; r < FUSED_RB; r++) OP::add(acc[r], q, cur[r]);
+            for (int k = 0; k < FUSED_CG; k++) {
+                if (c0 + k < p.nch) {
+                    const u4 q = *(const u4 *)(qv + (c0 + k) * 1024u + loff);
 #pragma unroll
-            for (int r = 0; r < FUSED_RB; r++) cur[r] = nxt[r];
+                    for (int r = 0; r < FUSED_RB; r++) OP::add(acc[r], q, rv[r][k]);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < FUSED_RB; r++) {
@@ -156,6 +163,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     for (;;) {
         if (cx.status != FS_OK) break;
         // pop the nearest candidate (lane 0), decide whether to stop
+        const bool tm = (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
         if (lane == 0) {
             uint32_t clen = cx.CTL[0]; const uint32_t wl = cx.CTL[1];
             uint32_t go = 0, cid = 0;
@@ -172,16 +180,20 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         __syncthreads();
         const uint32_t go = cx.CTL[3], cid = cx.CTL[4];
         __syncthreads();
+        if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[0] += t1 - t0; t0 = t1; }
         if (!go) break;
-        if (p.level[cid] < layer) continue;                                          // mod.rs:198-200
-        const uint32_t *nb; uint32_t n;
-        if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; n = p.l0_cnt[cid]; }
-        else { const uint32_t blk = p.up_block[cid] + (uint32_t)(layer - 1); nb = p.up_ids + (size_t)blk * p.m; n = p.up_cnt[blk]; }
+        // a linked element at layer 0 always has level >= 0, so the check of mod.rs:198-200 needs no load there
+        if (layer > 0 && p.level[cid] < layer) continue;
+        const uint32_t *nb; uint32_t n, lmax;
+        if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; lmax = 2u * p.m; }
+        else { nb = p.up_ids + (size_t)(p.up_block[cid] + (uint32_t)(layer - 1)) * p.m; lmax = p.m; }
+        const uint32_t e_first = lane < lmax ? nb[lane] : 0u;                        // issued together with the count: one memory hop
+        if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
         for (uint32_t n0 = 0; n0 < n; n0 += 64) {                                    // lists longer than a wave (m > 32) go in order
             const uint32_t idx = n0 + lane;
             uint32_t e = 0; bool unvis = false;
             if (idx < n) {
-                e = nb[idx];
+                e = n0 == 0 ? e_first : nb[idx];
                 const uint32_t bit = 1u << (e & 31u);
                 const uint32_t old = atomicOr(&cx.vis[e >> 5], bit);                 // visited.contains / insert, mod.rs:206-209
                 unvis = (old & bit) == 0;
@@ -192,13 +204,27 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             if (cnt == 0) continue;
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
             __syncthreads();
+            if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[1] += t1 - t0; t0 = t1; }
             const float mine = f_dist_batch<OP>(p, cx.QV, cx.IDS, cnt, lane);
             if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
             cx.nd0 += cnt;
+            // Pre-filter in parallel: once W is full (result_len >= ef) its furthest distance f only shrinks while this
+            // list is replayed, so a row with d >= f NOW can never be added later in the replay; lane 0 then visits only the
+            // survivors, in list order, and re-tests each against the current f -- same pushes, same order, as mod.rs:226-243.
+            const uint32_t wl0 = cx.CTL[1], rlen0 = cx.CTL[2];
+            bool keep = lane < cnt;
+            if (keep && rlen0 >= ef && wl0 && !(p.fdbg & 1u)) {
+                const float f0 = fh_d(cx.W[0]);
+                keep = scan ? !((double)mine >= (double)f0) : (mine < f0);
+            }
+            const unsigned long long kmask = __ballot(keep);
+            if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[2] += t1 - t0; t0 = t1; }
             __syncthreads();
             if (lane == 0) {                                                         // replay in list order, mod.rs:226-243 / scan.rs:372-429
                 uint32_t clen = cx.CTL[0], wl = cx.CTL[1], rlen = cx.CTL[2];
-                for (uint32_t j = 0; j < cnt; j++) {
+                unsigned long long km = kmask;
+                while (km) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(km); km &= km - 1ull;
                     const uint2 it = cx.RES[j]; const float d = fh_d(it);
                     const bool always_add = rlen < ef;
                     bool add;
@@ -213,6 +239,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
                 cx.CTL[0] = clen; cx.CTL[1] = wl; cx.CTL[2] = rlen;
             }
             __syncthreads();
+            if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[3] += t1 - t0; t0 = t1; }
             cx.status = __shfl(cx.status, 0, 64);
             if (cx.status != FS_OK) break;
         }
@@ -258,6 +285,7 @@ k_fused(const FusedParams p)
     cx.lane = threadIdx.x;
     cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
     cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
+    for (int i = 0; i < 5; i++) cx.tph[i] = 0;
     const uint32_t lane = cx.lane;
 
     for (;;) {
@@ -354,7 +382,8 @@ k_fused(const FusedParams p)
         }
         __syncthreads();
     }
-    if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax); }
+    if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax);
+                     if (p.fdbg & 4u) { for (int i = 0; i < 4; i++) atomicAdd(&p.n_dist[3 + i], cx.tph[i]); } }
 }
 
 // ---- device graph mirror maintenance ------------------------------------------------------------------------
@@ -461,6 +490,9 @@ int hx_engine::mirror_update(uint32_t first, uint32_t n_new, const int32_t *leve
 // =================================================================================================
 #define LK_MAXN 33            /* lm + 1 with lm <= 32 */
 #define LK_STAGE 5
+#ifndef LK_MINW
+#define LK_MINW 4
+#endif
 
 struct LinksParams {
     const uint8_t *rows; uint32_t pitch, m;
@@ -471,7 +503,7 @@ struct LinksParams {
 };
 
 template <class OP>
-__global__ void __launch_bounds__(HX_PAIR_WG, 4)
+__global__ void __launch_bounds__(HX_PAIR_WG, LK_MINW)
 k_links(const LinksParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -576,8 +608,8 @@ k_links(const LinksParams p)
             }
         }
         {
-            float res0, res1;
-            reduce_pairs<OP, HX_PAIRS_PER_WAVE>(acc, lane, res0, res1);
+            float res0 = 0.f, res1 = 0.f;
+            if (!(p.dbg & 32u)) reduce_pairs<OP, HX_PAIRS_PER_WAVE>(acc, lane, res0, res1);
             // lane l holds accumulator l (< 64); lanes 0,1 also hold accumulators 64, 65
 #pragma unroll
             for (int part = 0; part < 2; part++) {
@@ -629,6 +661,11 @@ static hipError_t launch_links(hx_engine *e, const LinksParams &p)
         hipError_t s = hipFuncSetAttribute((const void *)k_links<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         if (s != hipSuccess) return s;
         attr_set = true;
+    }
+    if (getenv("HX_DEBUG")) {
+        static thread_local bool once = false;
+        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_links<OP>, HX_PAIR_WG, lds);
+            fprintf(stderr, "[hx] k_links: dynamic LDS %zu B, occupancy API says %d blocks/CU\n", lds, nb); }
     }
     hipLaunchKernelGGL((k_links<OP>), dim3(p.n_groups), dim3(HX_PAIR_WG), lds, e->stream, p);
     return hipGetLastError();
@@ -704,6 +741,11 @@ static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid
         if (s != hipSuccess) return s;
         attr_set = true;
     }
+    if (getenv("HX_DEBUG")) {
+        static thread_local bool once = false;
+        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_fused<OP, MODE>, 64, lds);
+            fprintf(stderr, "[hx] k_fused<mode %d>: dynamic LDS %zu B, grid %u, occupancy API says %d blocks/CU\n", MODE, lds, grid, nb); }
+    }
     hipLaunchKernelGGL((k_fused<OP, MODE>), dim3(grid), dim3(64), lds, e->stream, p);
     return hipGetLastError();
 }
@@ -776,9 +818,10 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     p.m = mr.m; p.entry = entry; p.entry_level = entry_level;
     p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(mr.d_io + o_q); p.t_level = (const int32_t *)(mr.d_io + o_lv);
     p.ef = ef; p.k = k; p.ccap = ccap;
+    { const char *dv = getenv("HX_F_DBG"); p.fdbg = dv ? (uint32_t)atoi(dv) : 0u; }
     p.vis = mr.d_vis; p.vis_words = vis_words;
     p.next_task = (uint32_t *)(mr.d_io + o_ctr);
-    p.n_dist = (unsigned long long *)(mr.d_io + o_ctr + 16);
+    p.n_dist = (unsigned long long *)(mr.d_io + o_ctr + 8);
     p.out_ids = (uint32_t *)(mr.d_io + o_ids); p.out_d = (float *)(mr.d_io + o_d); p.out_cnt = (uint32_t *)(mr.d_io + o_cnt);
     p.status = (uint32_t *)(mr.d_io + o_st);
     if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
@@ -797,7 +840,8 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
     memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
     memcpy(out_d, mr.h_io + o_d, out_n * 4);
-    unsigned long long nd[3]; memcpy(nd, mr.h_io + o_ctr + 16, 24);
+    unsigned long long nd[7]; memcpy(nd, mr.h_io + o_ctr + 8, 56);
+    if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4)) fprintf(stderr, "[hx] k_fused mode %d phase clocks (sum over waves, 100 MHz ticks): pop %llu list+visited %llu dist %llu replay %llu; tasks %u\n", mode, nd[3], nd[4], nd[5], nd[6], ntasks);
     if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }
     if (nd[2] > fused_cmax) fused_cmax = nd[2];
     if (timing) {
