@@ -165,8 +165,8 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
  *   search : find_element_neighbors for members [lo, hi) of the batch (this rank's slice)
  *   export_new / import_new : serialized neighbour lists of members, exchanged with an all-gather
  *   links  : duplicate merge + entry point (every rank), then update_neighbor_connections for the lists this
- *            rank owns (owner = target row id % world)
- *   export_links / import_links : the updated lists of one owner, exchanged with an all-gather
+ *            rank owns (owner = target row id % world; only those ops are grouped and pruned here)
+ *   export_links / import_links : the lists a rank pruned, as self-describing records, exchanged with an all-gather
  *   end    : closes the batch; elem_out[i] = element holding tid i
  * hx_index_insert is begin, search(0,b), links(0,1), end. */
 int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids);
@@ -175,9 +175,9 @@ uint64_t hx_index_batch_new_bytes(const hx_index *ix, uint32_t lo, uint32_t hi);
 int hx_index_batch_export_new(const hx_index *ix, uint32_t lo, uint32_t hi, void *buf);
 int hx_index_batch_import_new(hx_index *ix, uint32_t lo, uint32_t hi, const void *buf);
 int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world);
-uint64_t hx_index_batch_links_bytes(const hx_index *ix, uint32_t owner, uint32_t world);
-int hx_index_batch_export_links(const hx_index *ix, uint32_t owner, uint32_t world, void *buf);
-int hx_index_batch_import_links(hx_index *ix, uint32_t owner, uint32_t world, const void *buf);
+uint64_t hx_index_batch_links_bytes(const hx_index *ix);                          /* size of this rank's own export */
+int hx_index_batch_export_links(const hx_index *ix, void *buf);                  /* self-describing records: target, layer, list */
+int hx_index_batch_import_links(hx_index *ix, const void *buf, uint64_t nbytes); /* any rank's export */
 int hx_index_batch_end(hx_index *ix, uint32_t *elem_out);
 
 /* graph export (what create_graph_pages/write_neighbor_tuples serialise, build.rs:545-821) */

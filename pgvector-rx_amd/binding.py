@@ -69,9 +69,9 @@ def lib():
         "hx_index_batch_export_new": (i32, [vp, u32, u32, vp]),
         "hx_index_batch_import_new": (i32, [vp, u32, u32, vp]),
         "hx_index_batch_links": (i32, [vp, u32, u32]),
-        "hx_index_batch_links_bytes": (u64, [vp, u32, u32]),
-        "hx_index_batch_export_links": (i32, [vp, u32, u32, vp]),
-        "hx_index_batch_import_links": (i32, [vp, u32, u32, vp]),
+        "hx_index_batch_links_bytes": (u64, [vp]),
+        "hx_index_batch_export_links": (i32, [vp, vp]),
+        "hx_index_batch_import_links": (i32, [vp, vp, u64]),
         "hx_index_batch_end": (i32, [vp, vp]),
         "hx_index_size": (u32, [vp]),
         "hx_index_entry": (i64, [vp]),
@@ -289,18 +289,17 @@ class Index:
     def batch_links(self, rank, world):
         self._ck(lib().hx_index_batch_links(self.h, rank, world))
 
-    def batch_links_bytes(self, owner, world):
-        return lib().hx_index_batch_links_bytes(self.h, owner, world)
+    def batch_links_bytes(self):
+        return lib().hx_index_batch_links_bytes(self.h)
 
-    def batch_export_links(self, owner, world):
-        buf = np.empty(self.batch_links_bytes(owner, world), np.uint8)
-        self._ck(lib().hx_index_batch_export_links(self.h, owner, world, _p(buf)))
+    def batch_export_links(self):
+        buf = np.empty(self.batch_links_bytes(), np.uint8)
+        self._ck(lib().hx_index_batch_export_links(self.h, _p(buf)))
         return buf
 
-    def batch_import_links(self, owner, world, buf):
+    def batch_import_links(self, buf):
         buf = np.ascontiguousarray(buf, np.uint8)
-        assert buf.nbytes == self.batch_links_bytes(owner, world)
-        self._ck(lib().hx_index_batch_import_links(self.h, owner, world, _p(buf)))
+        self._ck(lib().hx_index_batch_import_links(self.h, _p(buf), buf.nbytes))
 
     def batch_end(self, n):
         out = np.empty(n, np.uint32)

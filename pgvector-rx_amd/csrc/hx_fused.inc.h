@@ -394,7 +394,7 @@ __global__ void k_mirror_levels(int32_t *level, uint32_t *up_block, uint32_t fir
 }
 // one 64-thread block per record: {elem, layer, cnt, block} + ids[stride] + dists[stride]
 __global__ void k_mirror_lists(uint32_t *l0_ids, float *l0_d, uint16_t *l0_cnt, uint32_t *up_ids, float *up_d, uint16_t *up_cnt, uint32_t m,
-                               uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids, const float *dd, uint32_t stride)
+                               uint32_t n_rec, const uint32_t *hdr, const uint32_t *ids, const float *dd, uint32_t stride, uint8_t *pm_valid)
 {
     const uint32_t r = blockIdx.x;
     if (r >= n_rec) return;
@@ -402,7 +402,7 @@ __global__ void k_mirror_lists(uint32_t *l0_ids, float *l0_d, uint16_t *l0_cnt, 
     const uint32_t *src = ids + (size_t)r * stride; const float *sd = dd + (size_t)r * stride;
     if (layer == 0) {
         for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) { l0_ids[(size_t)elem * 2u * m + k] = src[k]; l0_d[(size_t)elem * 2u * m + k] = sd[k]; }
-        if (threadIdx.x == 0) l0_cnt[elem] = (uint16_t)cnt;
+        if (threadIdx.x == 0) { l0_cnt[elem] = (uint16_t)cnt; if (pm_valid) pm_valid[elem] = 0; }   // a list written by the host: cached pair matrix is stale
     } else {
         for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) { up_ids[(size_t)blk * m + k] = src[k]; up_d[(size_t)blk * m + k] = sd[k]; }
         if (threadIdx.x == 0) up_cnt[blk] = (uint16_t)cnt;
@@ -473,7 +473,7 @@ int hx_engine::mirror_update(uint32_t first, uint32_t n_new, const int32_t *leve
     if (n_new) hipLaunchKernelGGL(k_mirror_levels, dim3((n_new + 255) / 256), dim3(256), 0, stream, mr.d_level, mr.d_up_block, first, n_new,
                                   (const int32_t *)(mr.d_stage + o_lv), (const uint32_t *)(mr.d_stage + o_bk));
     if (n_rec) hipLaunchKernelGGL(k_mirror_lists, dim3(n_rec), dim3(64), 0, stream, mr.d_l0_ids, mr.d_l0_d, mr.d_l0_cnt, mr.d_up_ids, mr.d_up_d, mr.d_up_cnt, mr.m, n_rec,
-                                  (const uint32_t *)(mr.d_stage + o_hdr), (const uint32_t *)(mr.d_stage + o_ids), (const float *)(mr.d_stage + o_dd), stride);
+                                  (const uint32_t *)(mr.d_stage + o_hdr), (const uint32_t *)(mr.d_stage + o_ids), (const float *)(mr.d_stage + o_dd), stride, mr.d_pm_valid);
     HX_HIP(this, hipGetLastError());
     HX_HIP(this, hipStreamSynchronize(stream));
     return HX_OK;
@@ -652,6 +652,139 @@ k_links(const LinksParams p)
     if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, pairs); }
 }
 
+// =================================================================================================
+// K4b k_links_cached: the same update_neighbor_connections, one WAVEFRONT per (target, layer) list, with the list's pair
+//   matrix kept resident in HBM between batches (layer 0: 496 f32 per element = 2 GB per 1M rows -- cheap on 288 GB).
+//   A prune of a full list then needs only the 32 distances new-row <-> current neighbours (streamed exactly like an
+//   expansion: new row parked in LDS, neighbour rows 4 x 3 KiB at a time, canonical order) instead of all 528 pairs;
+//   select_neighbors runs on the cached matrix + those 32, and the matrix of the surviving list is written back.
+//   Pairs the cache does not hold yet (a list's first prune, or after the host rewrote the list) are computed first,
+//   row by row.  Cached values are the very bits a recomputation would give, so results equal k_links / the lock-step path.
+// =================================================================================================
+#define LC_SLOTS 32
+#define LC_TRI (LC_SLOTS * (LC_SLOTS - 1) / 2)     /* 496 */
+__device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > j ? i * (i - 1) / 2 + j : j * (j - 1) / 2 + i; }
+
+template <class OP>
+__global__ void __launch_bounds__(64, 4)
+k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    float *M = (float *)lds;                       // pair matrix over list slots, packed lower triangle [528]
+    float *M2 = M + 528;
+    uint32_t *lid = (uint32_t *)(M2 + 528);        // list ids / distances to the target [40]
+    float *ld = (float *)(lid + 40);
+    uint32_t *lid2 = (uint32_t *)(ld + 40); float *ld2 = (float *)(lid2 + 40);
+    float *nd = ld2 + 40;                          // d(new row, slot j)
+    uint32_t *pos = (uint32_t *)(nd + 40);         // sorted candidate k -> slot (LC_SLOTS = the new row)
+    float *sd = (float *)(pos + 40);
+    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *IDS = dis + 40;   // IDS[64]
+    uint8_t *QV = (uint8_t *)(IDS + 64);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t g = blockIdx.x;
+    if (g >= p.n_groups) return;
+    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u;
+    const uint32_t target = p.target[g], layer = p.layer[g];
+    const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
+    uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
+    if (layer == 0) { gl_ids = p.l0_ids + (size_t)target * 2u * p.m; gl_d = p.l0_d + (size_t)target * 2u * p.m; gl_cnt = p.l0_cnt + target; }
+    else { const uint32_t blk = p.up_block[target] + layer - 1; gl_ids = p.up_ids + (size_t)blk * p.m; gl_d = p.up_d + (size_t)blk * p.m; gl_cnt = p.up_cnt + blk; }
+    uint32_t cnt = *gl_cnt;
+    const bool cached = layer == 0 && lm == LC_SLOTS && pm != nullptr;
+    uint32_t v = cached ? pm_valid[target] : 0u;                 // slots [0, v) have their pairs in the cache
+    if (v > cnt) v = 0;
+    if (lane < cnt) { lid[lane] = gl_ids[lane]; ld[lane] = gl_d[lane]; }
+    if (v > 1) { const float *src = pm + (size_t)target * LC_TRI; for (uint32_t i = lane; i < v * (v - 1) / 2; i += 64) M[i] = src[i]; }
+    __syncthreads();
+    unsigned long long ndist = 0;
+
+    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
+        const uint32_t new_id = p.op_new[op]; const float new_d = p.op_d[op];
+        if (cnt < lm) {                                                            // mod.rs:469-471
+            if (lane == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
+            cnt++;
+            __syncthreads();
+            continue;
+        }
+        // pairs among the current list that the cache lacks: slot s against slots < s
+        for (uint32_t sl = v < 1 ? 1 : v; sl < cnt; sl++) {
+            if (lane < sl) IDS[lane] = lid[lane];
+            f_park(fp, p.rows + (size_t)lid[sl] * p.pitch, lane, QV);
+            const float d = f_dist_batch<OP>(fp, QV, IDS, sl, lane);
+            if (lane < sl) M[sl * (sl - 1) / 2 + lane] = d;
+            ndist += sl;
+            __syncthreads();
+        }
+        v = cnt;
+        // the new row against every slot
+        if (lane < cnt) IDS[lane] = lid[lane];
+        f_park(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
+        {
+            const float d = f_dist_batch<OP>(fp, QV, IDS, cnt, lane);
+            if (lane < cnt) nd[lane] = d;
+            ndist += cnt;
+        }
+        const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
+        __syncthreads();
+        if (lane < n) {
+            const float d = lane < cnt ? ld[lane] : new_d; uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) { const float dj = j < cnt ? ld[j] : new_d; rank += (dj < d) || (dj == d && j < lane); }
+            pos[rank] = lane < cnt ? lane : LC_SLOTS; sd[rank] = d;
+        }
+        __syncthreads();
+        // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
+        uint32_t r = 0, ndc = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (r >= lm) break;
+            const float ed = sd[i]; const uint32_t si = pos[i];
+            bool hit = false;
+            if (lane < r) {
+                const uint32_t sj = pos[sel[lane]];
+                const float dij = si == LC_SLOTS ? nd[sj] : (sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)]);
+                hit = dij <= ed;                                                   // mod.rs:333-335
+            }
+            const bool closer = __ballot(hit) == 0ull;
+            if (lane == 0) { if (closer) sel[r] = i; else dis[ndc] = i; }
+            if (closer) r++; else ndc++;
+            __syncthreads();
+        }
+        if (lane == 0) for (uint32_t j = 0; j < ndc && r < lm; j++) sel[r++] = dis[j];   // mod.rs:300-305
+        r = __shfl(r, 0, 64);
+        __syncthreads();
+        // surviving list and its pair matrix
+        if (lane < r) { const uint32_t sa = pos[sel[lane]]; lid2[lane] = sa == LC_SLOTS ? new_id : lid[sa]; ld2[lane] = sd[sel[lane]]; }
+        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) {
+            uint32_t a, b; tri_decode(idx, a, b);
+            const uint32_t sa = pos[sel[a]], sb = pos[sel[b]];
+            M2[idx] = sa == LC_SLOTS ? nd[sb] : (sb == LC_SLOTS ? nd[sa] : M[lc_tri(sa, sb)]);
+        }
+        __syncthreads();
+        if (lane < r) { lid[lane] = lid2[lane]; ld[lane] = ld2[lane]; }
+        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) M[idx] = M2[idx];
+        cnt = r; v = r;
+        __syncthreads();
+    }
+    if (lane < cnt) {
+        gl_ids[lane] = lid[lane]; gl_d[lane] = ld[lane];
+        p.out_ids[(size_t)g * 2u * p.m + lane] = lid[lane]; p.out_d[(size_t)g * 2u * p.m + lane] = ld[lane];
+    }
+    if (cached) {
+        float *dst = pm + (size_t)target * LC_TRI;
+        for (uint32_t i = lane; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64) dst[i] = M[i];
+        if (lane == 0) pm_valid[target] = (uint8_t)v;
+    }
+    if (lane == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
+}
+
+template <class OP>
+static hipError_t launch_links_cached(hx_engine *e, const LinksParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (528 * 2 + 40 * 10 + 64) * 4 + nch * 1024;
+    hipLaunchKernelGGL((k_links_cached<OP>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    return hipGetLastError();
+}
+
 template <class OP>
 static hipError_t launch_links(hx_engine *e, const LinksParams &p)
 {
@@ -678,6 +811,23 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     if (n_groups == 0) return HX_OK;
     if (2 * mr.m + 1 > LK_MAXN) return fail(HX_E_ARG, "k_links handles m <= 16");
     HX_HIP(this, hipSetDevice(device));
+    static const bool use_cache = !(getenv("HX_LINKS_NOCACHE") && atoi(getenv("HX_LINKS_NOCACHE")));
+    if (use_cache && 2 * mr.m == LC_SLOTS && pitch <= FUSED_MAXCH * 1024u && mr.cap_pm < mr.cap) {
+        // pair-matrix cache for every layer-0 list: 496 f32 per element
+        float *npm = nullptr; uint8_t *nv = nullptr;
+        HX_HIP(this, hipMalloc((void **)&npm, (size_t)mr.cap * LC_TRI * sizeof(float)));
+        HX_HIP(this, hipMalloc((void **)&nv, mr.cap));
+        HX_HIP(this, hipMemsetAsync(nv, 0, mr.cap, stream));
+        if (mr.d_pm && mr.cap_pm) {
+            HX_HIP(this, hipMemcpyAsync(npm, mr.d_pm, (size_t)mr.cap_pm * LC_TRI * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HX_HIP(this, hipMemcpyAsync(nv, mr.d_pm_valid, mr.cap_pm, hipMemcpyDeviceToDevice, stream));
+        }
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (mr.d_pm) (void)hipFree(mr.d_pm);
+        if (mr.d_pm_valid) (void)hipFree(mr.d_pm_valid);
+        mr.d_pm = npm; mr.d_pm_valid = nv; mr.cap_pm = mr.cap;
+    }
+    const bool cached_kernel = use_cache && mr.d_pm != nullptr && 2 * mr.m == LC_SLOTS;
     const uint32_t n_ops = op_off[n_groups], lm0 = 2 * mr.m;
     size_t o = 0;
     const size_t o_ctr = o; o += 64;
@@ -715,11 +865,19 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
-#define F32C(K) ls = launch_links<OpF32<K>>(this, p)
-#define F16C(K) ls = launch_links<OpF16<K>>(this, p)
-    HX_DISPATCH(this, F32C, F16C, ls = launch_links<OpHamming>(this, p), ls = launch_links<OpJaccard>(this, p));
+    if (cached_kernel) {
+#define F32C(K) ls = launch_links_cached<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_links_cached<OpF16<K>>(this, p)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links_cached<OpHamming>(this, p), ls = launch_links_cached<OpJaccard>(this, p));
 #undef F32C
 #undef F16C
+    } else {
+#define F32C(K) ls = launch_links<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_links<OpF16<K>>(this, p)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links<OpHamming>(this, p), ls = launch_links<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+    }
     HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
     HX_HIP(this, hipMemcpyAsync(h + o_ctr, mr.d_lk + o_ctr, 64, hipMemcpyDeviceToHost, stream));

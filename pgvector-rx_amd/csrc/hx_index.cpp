@@ -907,7 +907,11 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
                 if (opstart[i + 1] == o) continue;
                 for (int lc = g.level[id]; lc >= 0; lc--) {
                     const Cand *lst = g.list(id, lc);
-                    for (uint16_t k = 0; k < g.cnt(id, lc); k++) { raw[o++] = BackOp{lst[k].id, lc, id, lst[k].d}; h[lst[k].id & (NB - 1)]++; }
+                    for (uint16_t k = 0; k < g.cnt(id, lc); k++) {
+                        raw[o] = BackOp{lst[k].id, lc, id, lst[k].d};
+                        if (lst[k].id % world == rank) h[lst[k].id & (NB - 1)]++; else raw[o].layer = -1;   // another rank prunes that list
+                        o++;
+                    }
                 }
             }
         });
@@ -915,11 +919,11 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         for (uint32_t bk = 0; bk < NB; bk++) { uint32_t t = 0; for (uint32_t c = 0; c < nck; c++) t += hist[(size_t)c * NB + bk]; bstart[bk + 1] = bstart[bk] + t; }
         // per (chunk, bucket) write cursor = bucket start + ops of earlier chunks in that bucket (keeps insertion order)
         for (uint32_t bk = 0; bk < NB; bk++) { uint32_t run = bstart[bk]; for (uint32_t c = 0; c < nck; c++) { const uint32_t t = hist[(size_t)c * NB + bk]; hist[(size_t)c * NB + bk] = run; run += t; } }
-        ops.resize(n_ops);
+        ops.resize(bstart[NB]);
         ix->pool->parallel_for(nck, [&](size_t ci) {
             uint32_t *cur = &hist[ci * NB];
             const uint32_t lo = opstart[std::min<size_t>(b, ci * csz)], hi = opstart[std::min<size_t>(b, (ci + 1) * csz)];
-            for (uint32_t o = lo; o < hi; o++) ops[cur[raw[o].target & (NB - 1)]++] = raw[o];
+            for (uint32_t o = lo; o < hi; o++) if (raw[o].layer >= 0) ops[cur[raw[o].target & (NB - 1)]++] = raw[o];
         });
         std::vector<std::vector<std::pair<size_t, size_t>>> bgrp(NB);
         ix->pool->parallel_for(NB, [&](size_t bk) {
@@ -988,25 +992,55 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
 }
 
 // serialized lists owned by `owner` after the links stage, in (target, layer) order -- every rank derives the same order
-uint64_t hx_index_batch_links_bytes(const hx_index *ix, uint32_t owner, uint32_t world)
+// serialized lists this rank pruned in the links stage (it grouped only the ops whose target it owns), self-describing:
+// per list u32 target, u32 layer, then the list record (u32 count, lm x {u32 id, f32 d})
+uint64_t hx_index_batch_links_bytes(const hx_index *ix)
 {
-    if (!ix || !ix->bs.open || !ix->bs.linked || world == 0) return 0;
+    if (!ix || !ix->bs.open || !ix->bs.linked) return 0;
     uint64_t n = 0;
-    for (const auto &gr : ix->bs.grp) if (ix->bs.ops[gr.first].target % world == owner) n += list_bytes(ix->g, ix->bs.ops[gr.first].layer);
+    for (const auto &gr : ix->bs.grp) n += 8 + list_bytes(ix->g, ix->bs.ops[gr.first].layer);
     return n;
 }
-int hx_index_batch_export_links(const hx_index *ix, uint32_t owner, uint32_t world, void *buf)
+int hx_index_batch_export_links(const hx_index *ix, void *buf)
 {
-    if (!ix || !buf || !ix->bs.open || !ix->bs.linked || world == 0) return HX_E_ARG;
-    uint8_t *p = (uint8_t *)buf;
-    for (const auto &gr : ix->bs.grp) { const BackOp &o = ix->bs.ops[gr.first]; if (o.target % world == owner) p = put_list(ix->g, o.target, o.layer, p); }
+    if (!ix || !buf || !ix->bs.open || !ix->bs.linked) return HX_E_ARG;
+    const BatchState &bs = ix->bs; const size_t ng = bs.grp.size();
+    std::vector<size_t> off(ng + 1, 0);
+    for (size_t k = 0; k < ng; k++) off[k + 1] = off[k] + 8 + list_bytes(ix->g, bs.ops[bs.grp[k].first].layer);
+    uint8_t *base = (uint8_t *)buf;
+    ix->pool->parallel_for((ng + 4095) / 4096, [&](size_t ci) {
+        for (size_t k = ci * 4096; k < std::min(ng, ci * 4096 + 4096); k++) {
+            const BackOp &o = bs.ops[bs.grp[k].first];
+            uint8_t *p = base + off[k];
+            const uint32_t ly = (uint32_t)o.layer;
+            memcpy(p, &o.target, 4); memcpy(p + 4, &ly, 4);
+            put_list(ix->g, o.target, o.layer, p + 8);
+        }
+    });
     return HX_OK;
 }
-int hx_index_batch_import_links(hx_index *ix, uint32_t owner, uint32_t world, const void *buf)
+int hx_index_batch_import_links(hx_index *ix, const void *buf, uint64_t nbytes)
 {
-    if (!ix || !buf || !ix->bs.open || !ix->bs.linked || world == 0) return HX_E_ARG;
-    const uint8_t *p = (const uint8_t *)buf;
-    for (const auto &gr : ix->bs.grp) { const BackOp &o = ix->bs.ops[gr.first]; if (o.target % world == owner) { p = get_list(ix->g, o.target, o.layer, p); ix->dirty.emplace_back(o.target, o.layer); } }
+    if (!ix || (!buf && nbytes) || !ix->bs.open || !ix->bs.linked) return HX_E_ARG;
+    Graph &g = ix->g;
+    const uint8_t *base = (const uint8_t *)buf;
+    std::vector<size_t> off;                                   // record boundaries (the record size depends on its layer)
+    for (size_t o = 0; o + 8 <= nbytes;) {
+        uint32_t tg, ly; memcpy(&tg, base + o, 4); memcpy(&ly, base + o + 4, 4);
+        if (tg >= g.size() || g.level[tg] < (int)ly) return ix->fail(HX_E_ARG, "corrupt link record");
+        off.push_back(o);
+        o += 8 + list_bytes(g, (int)ly);
+        if (o > nbytes) return ix->fail(HX_E_ARG, "truncated link record");
+    }
+    const size_t nr = off.size(), d0 = ix->dirty.size();
+    ix->dirty.resize(d0 + nr);
+    ix->pool->parallel_for((nr + 4095) / 4096, [&](size_t ci) {
+        for (size_t k = ci * 4096; k < std::min(nr, ci * 4096 + 4096); k++) {
+            uint32_t tg, ly; memcpy(&tg, base + off[k], 4); memcpy(&ly, base + off[k] + 4, 4);
+            get_list(g, tg, (int)ly, base + off[k] + 8);
+            ix->dirty[d0 + k] = {tg, (int)ly};
+        }
+    });
     return HX_OK;
 }
 

@@ -6,9 +6,9 @@ rows (288 GB of HBM per GPU makes that free) and of the graph, and each batch is
 
   search stage   rank r runs find_element_neighbors for a contiguous slice of the batch; the members' new
                  neighbour lists are exchanged with ONE all_gather (fixed-size records, padded per rank)
-  links stage    every rank applies duplicate merge / entry-point update identically, then prunes only the
-                 back-link lists it owns (owner = target row id % world); the updated lists are exchanged with
-                 ONE all_gather in an order all ranks derive identically
+  links stage    every rank applies duplicate merge / entry-point update identically, then groups and prunes only the
+                 back-link lists it owns (owner = target row id % world); the updated lists travel as self-describing
+                 records (target, layer, list) in ONE all_gather (plus a tiny all_gather of the payload sizes)
 
 so the graph after every batch is bit-identical on all ranks and identical to the single-GPU build with the same
 batch schedule.  The only data-path collectives are those two all_gathers per batch.  Batches smaller than
@@ -40,6 +40,14 @@ def exchange(payload, sizes, rank, dist, device):
     return [host[r * cap:r * cap + sizes[r]] for r in range(world)]
 
 
+def gather_sizes(n, dist, device):
+    """Payload sizes of all ranks (the links stage groups only the ops a rank owns, so sizes are not known elsewhere)."""
+    world = dist.get_world_size()
+    out = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, torch.tensor([n], dtype=torch.int64, device=device))
+    return [int(x) for x in out.cpu().tolist()]
+
+
 def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_shard=256, size_fn=None):
     """hx_index_insert for rows [first_row, first_row + len(levels)) with every batch shared by the ranks.
     `ix` exposes the staged batch API of binding.Index (tests drive this with a stand-in object and gloo)."""
@@ -66,11 +74,11 @@ def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_sh
             if r != rank and sizes[r]:
                 ix.batch_import_new(lo[r], hi[r], buf)
         ix.batch_links(rank, world)
-        sizes = [ix.batch_links_bytes(r, world) for r in range(world)]
-        mine = ix.batch_export_links(rank, world)
+        mine = ix.batch_export_links()
+        sizes = gather_sizes(len(mine), dist, device)
         for r, buf in enumerate(exchange(mine, sizes, rank, dist, device)):
             if r != rank and sizes[r]:
-                ix.batch_import_links(r, world, buf)
+                ix.batch_import_links(buf)
         elems[done:done + b] = ix.batch_end(b)
         done += b
     return elems

@@ -117,21 +117,27 @@ class FakeIndex:
                 self.link_tok[t] = tok
                 self.calls["links_owned"] += 1
 
-    def batch_links_bytes(self, owner, world):
-        return sum(4 + lm(0) * 8 for t, _ in self.open["groups"] if t % world == owner)
+    def batch_links_bytes(self):
+        rank, world = self.open["rank"], self.open["world"]
+        return sum(8 + 4 + lm(0) * 8 for t, _ in self.open["groups"] if t % world == rank)
 
-    def batch_export_links(self, owner, world):
+    def batch_export_links(self):
+        rank, world = self.open["rank"], self.open["world"]
         n = 4 + lm(0) * 8
-        parts = [np.resize(np.frombuffer(self.link_tok[t].to_bytes(8, "little"), np.uint8), n)
-                 for t, _ in self.open["groups"] if t % world == owner]
+        parts = []
+        for t, _ in self.open["groups"]:
+            if t % world == rank:
+                parts.append(np.frombuffer(np.asarray([t, 0], np.uint32).tobytes(), np.uint8))
+                parts.append(np.resize(np.frombuffer(self.link_tok[t].to_bytes(8, "little"), np.uint8), n))
         return np.concatenate(parts) if parts else np.empty(0, np.uint8)
 
-    def batch_import_links(self, owner, world, buf):
+    def batch_import_links(self, buf):
         n, off = 4 + lm(0) * 8, 0
-        for t, _ in self.open["groups"]:
-            if t % world == owner:
-                self.link_tok[t] = int.from_bytes(bytes(buf[off:off + 8]), "little")
-                off += n
+        while off < len(buf):
+            t = int(np.frombuffer(bytes(buf[off:off + 4]), np.uint32)[0])
+            assert t % self.open["world"] != self.open["rank"]                 # only other ranks' lists arrive
+            self.link_tok[t] = int.from_bytes(bytes(buf[off + 8:off + 16]), "little")
+            off += 8 + n
         assert off == len(buf)
 
     def batch_end(self, b):

@@ -324,11 +324,11 @@ def test_staged_batches_two_rank_simulation(fused):
                     ix.batch_import_new(lo[s], hi[s], bufs[s])
         for r, (_, ix) in enumerate(ranks):
             ix.batch_links(r, world)
-        bufs = [ix.batch_export_links(r, world) for r, (_, ix) in enumerate(ranks)]
+        bufs = [ix.batch_export_links() for _, ix in ranks]
         for r, (_, ix) in enumerate(ranks):
             for s in range(world):
                 if s != r and len(bufs[s]):
-                    ix.batch_import_links(s, world, bufs[s])
+                    ix.batch_import_links(bufs[s])
             ix.batch_end(b)
         done += b
     for _, ix in ranks:
