@@ -20,6 +20,7 @@
 #define FUSED_MAXCH 8          /* 1 KiB chunks per row: pitch <= 8192 B covers vector(2000), halfvec(4000), bit(64000) */
 #define FUSED_RB 4             /* rows in flight per wave ... */
 #define FUSED_CG 3             /* ... times chunks of each requested at once */
+#define FUSED_CCAP 8192u       /* candidate-heap capacity per search (LDS head + global spill) */
 #define FUSED_MAXL 8           /* layers 0..7 handled on the device (P(level >= 8) = 16^-8 at m=16) */
 enum { FS_OK = 0, FS_OVERFLOW = 1, FS_HOST = 2 };
 
@@ -29,8 +30,9 @@ struct FusedParams {
     const uint32_t *up_block, *up_ids; const uint16_t *up_cnt;
     uint32_t m, entry; int32_t entry_level;
     uint32_t ntasks; const uint32_t *t_qsel; const int32_t *t_level;
-    uint32_t ef, k, ccap;
-    uint32_t *vis; uint64_t vis_words;            // per-workgroup visited bitmap, vis_words 32-bit words each
+    uint32_t ef, k, ccap, clds;                  // ccap: capacity of the candidate heap, its first clds entries in LDS
+    uint2 *spill; uint32_t spill_stride;         // per-workgroup spill area of the candidate heap (entries)
+    uint32_t *vis; uint64_t vis_words;            // per-workgroup visited set: open-addressing table of vis_words (power of 2) row ids
     uint32_t *next_task;
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
@@ -41,45 +43,70 @@ struct FHeapItem { float d; uint32_t id; };
 __device__ __forceinline__ uint2 fh_pack(float d, uint32_t id) { return make_uint2(__builtin_bit_cast(unsigned int, d), id); }
 __device__ __forceinline__ float fh_d(const uint2 &v) { return __builtin_bit_cast(float, v.x); }
 
-// Rust std BinaryHeap on an LDS array; NEAREST: smallest distance on top.  Called by ONE lane.
+// Heap storage: the first `L` entries live in LDS, the rest in this workgroup's spill area in global memory (only lane 0
+// touches a heap, and a thread sees its own stores in program order).  Deep heaps are rare and only their bottom level
+// spills, so the common case never leaves LDS while the LDS budget per search stays small.
+struct HStore {
+    uint2 *lds, *glob; uint32_t L;
+    __device__ __forceinline__ uint2 get(uint32_t i) const { return i < L ? lds[i] : glob[i - L]; }
+    __device__ __forceinline__ void set(uint32_t i, uint2 v) const { if (i < L) lds[i] = v; else glob[i - L] = v; }
+};
+
+// Rust std BinaryHeap; NEAREST: smallest distance on top.  Called by ONE lane.
 template <bool NEAREST> struct FHeap {
     static __device__ __forceinline__ bool le(float a, float b) { return NEAREST ? !(b > a) : !(a > b); }
-    static __device__ void sift_up(uint2 *h, uint32_t start, uint32_t pos)
+    static __device__ void sift_up(const HStore &h, uint32_t start, uint32_t pos)
     {
-        const uint2 e = h[pos]; const float ed = fh_d(e);
+        const uint2 e = h.get(pos); const float ed = fh_d(e);
         while (pos > start) {
             const uint32_t parent = (pos - 1) >> 1;
-            const uint2 pv = h[parent];
+            const uint2 pv = h.get(parent);
             if (le(ed, fh_d(pv))) break;
-            h[pos] = pv; pos = parent;
+            h.set(pos, pv); pos = parent;
         }
-        h[pos] = e;
+        h.set(pos, e);
     }
-    static __device__ void push(uint2 *h, uint32_t &len, uint2 c) { h[len] = c; len++; sift_up(h, 0, len - 1); }
-    static __device__ uint2 pop(uint2 *h, uint32_t &len)      // len > 0
+    static __device__ void push(const HStore &h, uint32_t &len, uint2 c) { h.set(len, c); len++; sift_up(h, 0, len - 1); }
+    static __device__ uint2 pop(const HStore &h, uint32_t &len)      // len > 0
     {
-        uint2 item = h[len - 1]; len--;
+        uint2 item = h.get(len - 1); len--;
         if (len > 0) {
-            const uint2 top = h[0]; h[0] = item; item = top;
+            const uint2 top = h.get(0); h.set(0, item); item = top;
             // sift_down_to_bottom(0)
             const uint32_t end = len; uint32_t pos = 0;
-            const uint2 e = h[0];
+            const uint2 e = h.get(0);
             uint32_t child = 1;
             while (end >= 2 && child <= end - 2) {
-                const uint2 a = h[child], b = h[child + 1];
+                const uint2 a = h.get(child), b = h.get(child + 1);
                 const bool right = le(fh_d(a), fh_d(b));
-                h[pos] = right ? b : a; pos = child + (right ? 1u : 0u); child = 2 * pos + 1;
+                h.set(pos, right ? b : a); pos = child + (right ? 1u : 0u); child = 2 * pos + 1;
             }
-            if (child == end - 1) { h[pos] = h[child]; pos = child; }
-            h[pos] = e;
+            if (child == end - 1) { h.set(pos, h.get(child)); pos = child; }
+            h.set(pos, e);
             sift_up(h, 0, pos);
         }
         return item;
     }
 };
 
+// visited set (HashSet<usize> of graph/mod.rs:171): a per-workgroup open-addressing table of row ids in global memory,
+// small enough (32-64 KB) to stay in L2 / Infinity Cache however large the index is.  Lanes insert concurrently with
+// atomicCAS; returns true if the id was already present.
+#define VIS_EMPTY 0xffffffffu
+__device__ __forceinline__ uint32_t vis_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ bool vis_test_and_set(uint32_t *tab, uint32_t mask, uint32_t key)
+{
+    uint32_t h = vis_mix(key) & mask;
+    for (;;) {
+        const uint32_t old = atomicCAS(&tab[h], VIS_EMPTY, key);
+        if (old == VIS_EMPTY) return false;
+        if (old == key) return true;
+        h = (h + 1u) & mask;
+    }
+}
+
 struct FusedCtx {
-    uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV;
+    uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
     unsigned long long nd0, nd1; uint32_t cmax;
     unsigned long long tph[5];   // diagnostic phase clocks (HX_F_DBG & 4): pop, list+visited, distances, replay, other
@@ -147,14 +174,15 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
 {
     const uint32_t lane = cx.lane;
     // fresh visited set
-    for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{0u, 0u, 0u, 0u};
+    for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
+    uint32_t vcount = n_ep;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (uint32_t i = lane; i < n_ep; i += 64) { const uint32_t e = cx.EP[i].y; atomicOr(&cx.vis[e >> 5], 1u << (e & 31u)); }
+    for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)p.vis_words - 1u, cx.EP[i].y);
     if (lane == 0) {
         uint32_t clen = 0, wlen = 0;
         for (uint32_t i = 0; i < n_ep; i++) {
             if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
-            FHeap<true>::push(cx.C, clen, cx.EP[i]); FHeap<false>::push(cx.W, wlen, cx.EP[i]);
+            FHeap<true>::push(cx.CH, clen, cx.EP[i]); FHeap<false>::push(cx.WH, wlen, cx.EP[i]);
         }
         cx.CTL[0] = clen; cx.CTL[1] = wlen; cx.CTL[2] = wlen;     // C len, W len, result_len
     }
@@ -168,7 +196,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             uint32_t clen = cx.CTL[0]; const uint32_t wl = cx.CTL[1];
             uint32_t go = 0, cid = 0;
             if (clen > 0) {
-                const uint2 c = FHeap<true>::pop(cx.C, clen);
+                const uint2 c = FHeap<true>::pop(cx.CH, clen);
                 const float cd = fh_d(c);
                 bool stop;
                 if (!scan) { const float f = wl ? fh_d(cx.W[0]) : 3.402823466e+38f; stop = cd > f; }                     // mod.rs:188-193
@@ -194,13 +222,13 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             uint32_t e = 0; bool unvis = false;
             if (idx < n) {
                 e = n0 == 0 ? e_first : nb[idx];
-                const uint32_t bit = 1u << (e & 31u);
-                const uint32_t old = atomicOr(&cx.vis[e >> 5], bit);                 // visited.contains / insert, mod.rs:206-209
-                unvis = (old & bit) == 0;
+                unvis = !vis_test_and_set(cx.vis, (uint32_t)p.vis_words - 1u, e);    // visited.contains / insert, mod.rs:206-209
                 if (unvis && layer > 0 && p.level[e] < layer) unvis = false;         // mod.rs:213-216
             }
             const unsigned long long mask = __ballot(unvis);
             const uint32_t cnt = (uint32_t)__popcll(mask);
+            vcount += cnt;
+            if (vcount * 4u > (uint32_t)p.vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
             if (cnt == 0) continue;
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
             __syncthreads();
@@ -232,9 +260,9 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
                     else { const double f = wl ? (double)fh_d(cx.W[0]) : 1.7976931348623157e+308; add = !(!always_add && (double)d >= f); }
                     if (!add) continue;
                     if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
-                    FHeap<true>::push(cx.C, clen, it); FHeap<false>::push(cx.W, wl, it); rlen++;
+                    FHeap<true>::push(cx.CH, clen, it); FHeap<false>::push(cx.WH, wl, it); rlen++;
                     if (clen > cx.cmax) cx.cmax = clen;
-                    if (rlen > ef) { (void)FHeap<false>::pop(cx.W, wl); rlen--; }
+                    if (rlen > ef) { (void)FHeap<false>::pop(cx.WH, wl); rlen--; }
                 }
                 cx.CTL[0] = clen; cx.CTL[1] = wl; cx.CTL[2] = rlen;
             }
@@ -273,15 +301,17 @@ k_fused(const FusedParams p)
     // LDS carve: C[ccap] | W[ef+2] | EP[ef+2] | RES[64] | RL[2m] | IDS[64] CTL[16] | QV[nch KiB].  The select phase runs
     // after the layer's search is over, so its scratch (the candidate under test EV and the discarded list DL) reuses C.
     cx.C = (uint2 *)lds;
-    cx.W = cx.C + p.ccap;
+    cx.W = cx.C + p.clds;
     cx.EP = cx.W + (p.ef + 2);
     cx.RES = cx.EP + (p.ef + 2);
     cx.RL = cx.RES + 64;
     cx.IDS = (uint32_t *)(cx.RL + lm0);
     cx.CTL = cx.IDS + 64;
     cx.QV = (uint8_t *)(cx.CTL + 16);                     // query parked in LDS (nch KiB)
-    cx.EV = (uint8_t *)cx.C;                              // host guarantees ccap*8 >= nch*1024 + (ef+2)*8
+    cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
+    cx.CH.lds = cx.C; cx.CH.glob = p.spill + (size_t)blockIdx.x * p.spill_stride; cx.CH.L = p.clds;
+    cx.WH.lds = cx.W; cx.WH.glob = nullptr; cx.WH.L = 0xffffffffu;
     cx.lane = threadIdx.x;
     cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
     cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
@@ -926,21 +956,24 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
     HX_HIP(this, hipSetDevice(device));
     // LDS: C[ccap] W[ef+2] EP[ef+2] RES[64] RL[2m] DL[ef+2] (8 B each) + IDS[64] + CTL[16] (4 B each)
-    // candidate-heap budget: 9*ef entries covered the largest heap seen on 1M x 768 builds (1552 at ef = 200); a task that
-    // needs more reports FS_OVERFLOW and is re-run by the lock-step path
+    // candidate heap: up to FUSED_CCAP entries, the first `clds` in LDS and the tail in a per-workgroup spill area
+    // (the largest heap seen on 1M x 768 builds was 1552 entries at ef = 200); beyond FUSED_CCAP a task reports
+    // FS_OVERFLOW and is re-run by the lock-step path
     const size_t nch_ = (pitch + 1023) / 1024;
-    uint32_t ccap = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, ef * 9u));
-    ccap = std::max<uint32_t>(ccap, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));
+    const uint32_t ccap = FUSED_CCAP;
+    uint32_t clds = mode == 1 ? 1024u : 512u;
+    clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
     auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16) * 4 + nch_ * 1024; };
-    const size_t lds = lds_bytes(ccap);
+    const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
     const uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
-    const uint64_t vis_words = (((n_rows + 31) / 32) + 3) & ~3ull;
+    uint64_t vis_words = 4096; while (vis_words < (uint64_t)ef * 2 * mr.m * 2 + 1024) vis_words <<= 1;   // >= 2x the ids a search can touch at its usual ~ef expansions
+    if (!mr.d_spill) HX_HIP(this, hipMalloc((void **)&mr.d_spill, (size_t)256 * 16 * FUSED_CCAP * 8));
     if ((uint64_t)grid * vis_words > mr.cap_vis) {
         if (mr.d_vis) (void)hipFree(mr.d_vis);
         mr.d_vis = nullptr; mr.cap_vis = 0;
-        const uint64_t n = (uint64_t)256 * 16 * ((((std::max<uint64_t>(n_rows, capacity) + 31) / 32) + 3) & ~3ull);
+        const uint64_t n = (uint64_t)256 * 16 * vis_words;
         HX_HIP(this, hipMalloc((void **)&mr.d_vis, n * 4));
         mr.cap_vis = n;
     }
@@ -975,7 +1008,8 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     p.l0_ids = mr.d_l0_ids; p.l0_cnt = mr.d_l0_cnt; p.level = mr.d_level; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_cnt = mr.d_up_cnt;
     p.m = mr.m; p.entry = entry; p.entry_level = entry_level;
     p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(mr.d_io + o_q); p.t_level = (const int32_t *)(mr.d_io + o_lv);
-    p.ef = ef; p.k = k; p.ccap = ccap;
+    p.ef = ef; p.k = k; p.ccap = ccap; p.clds = clds;
+    p.spill = (uint2 *)mr.d_spill; p.spill_stride = FUSED_CCAP;
     { const char *dv = getenv("HX_F_DBG"); p.fdbg = dv ? (uint32_t)atoi(dv) : 0u; }
     p.vis = mr.d_vis; p.vis_words = vis_words;
     p.next_task = (uint32_t *)(mr.d_io + o_ctr);

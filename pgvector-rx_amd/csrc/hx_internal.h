@@ -45,6 +45,7 @@ struct HxMirror {
     uint8_t *h_lk = nullptr, *d_lk = nullptr; size_t cap_lk = 0;
     float *d_pm = nullptr; uint8_t *d_pm_valid = nullptr; uint64_t cap_pm = 0;   // resident pair matrices of the layer-0 lists
     uint32_t *d_vis = nullptr; uint64_t cap_vis = 0;
+    void *d_spill = nullptr;                 // candidate-heap spill areas of the fused kernel's workgroups
     uint8_t *h_stage = nullptr, *d_stage = nullptr; size_t cap_stage = 0;
     uint8_t *h_io = nullptr, *d_io = nullptr; size_t cap_io = 0;
 };
