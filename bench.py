@@ -169,6 +169,25 @@ def main():
     search_prof = ix.profile()
     qps = world * a.queries * a.steps / dt
 
+    # the batched L2 kernel of the lock-step placement (K1 k_dist_groups: query parked in LDS, coalesced row streaming,
+    # shuffle reduction) on the same resident table, at a lock-step-sized launch: 32768 expansions x 32 rows
+    k1 = None
+    if rank == 0:
+        rng = np.random.default_rng(5)
+        g_n, per = 32768, 2 * a.m
+        gq = rng.integers(0, a.rows, g_n).astype(np.uint32)
+        goff = (np.arange(g_n + 1) * per).astype(np.uint32)
+        gids = rng.integers(0, a.rows, g_n * per).astype(np.uint32)
+        eng.distances_batch(gq, goff, gids)
+        eng.kernel_stats(0, reset=True)
+        for _ in range(10):
+            eng.distances_batch(gq, goff, gids)
+        ks = eng.kernel_stats(0, reset=True)
+        k1_gbps = ks["units"] * a.dim * 4 / max(ks["ms"], 1e-9) / 1e6
+        k1 = {"kernel": "k_dist_groups", "bound": "hbm", "achieved": round(k1_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+              "frac": round(k1_gbps / HBM_PEAK_GBPS, 4), "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / ks["launches"], 4),
+              "distances_per_launch": g_n * per, "bytes_per_distance": a.dim * 4}
+
     gt = ground_truth(rows, queries, a.k)
     recall = recall_at_k(tids, cnt, gt, a.k)
     if world > 1:
@@ -279,6 +298,7 @@ def main():
         "build_rows_per_s": round(a.rows / build_sec, 1),
         "recall_at_10": round(recall, 4),
         "roofline": roofline,
+        "roofline_k1_batched_l2": k1,
         "cpu_baseline": cpu,
         "build_kernels": build_kernels,
         "host_profile": {"build": {k: round(v, 2) for k, v in build_prof.items()}, "search_all_steps": {k: round(v, 3) for k, v in search_prof.items()}},

@@ -344,3 +344,35 @@ def test_staged_batches_two_rank_simulation(fused):
     for e, ix in ranks + [(e0, ix0)]:
         ix.close()
         e.close()
+
+
+def test_fused_equals_lockstep_at_scale():
+    """BASELINE-sized rows (d=768) and a graph large enough for multi-level descent: the device-resident traversal and
+    the lock-step driver must return identical tids and distance bits, and both must agree with exact brute force to the
+    usual HNSW recall (size-independent properties; the oracle would take minutes at this size)."""
+    rng = np.random.default_rng(9)
+    n, dim, m, efc, efs, k, nq = 60_000, 768, 16, 64, 64, 10, 500
+    centres = rng.random((64, dim), dtype=np.float32)
+    rows = (centres[rng.integers(0, 64, n)] + 0.1 * rng.standard_normal((n, dim), dtype=np.float32)).astype(np.float32)
+    qs = (centres[rng.integers(0, 64, nq)] + 0.1 * rng.standard_normal((nq, dim), dtype=np.float32)).astype(np.float32)
+    levels = hx.draw_levels(n, m, seed=2)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    ix.insert(0, levels, batch=4096)
+    assert ix.fused_stats()["redone"] == 0
+    e.set_queries(qs)
+    a = ix.search(nq, efs, k)
+    ix.set_fused(False)
+    b = ix.search(nq, efs, k)
+    assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all() and (a[3] == b[3]).all()
+    d2 = (qs.astype(np.float64) ** 2).sum(1)[:, None] + (rows.astype(np.float64) ** 2).sum(1)[None, :] - 2.0 * qs.astype(np.float64) @ rows.astype(np.float64).T
+    exact = np.argsort(d2, axis=1)[:, :k]
+    recall = np.mean([len(set(a[0][q, :a[3][q]].tolist()) & set(exact[q].tolist())) / k for q in range(nq)])
+    assert recall >= 0.9, recall
+    # sortedness and exactness of the returned distances
+    assert (np.diff(a[1], axis=1) >= 0).all()
+    chk = ((rows[a[0][:, 0]].astype(np.float64) - qs.astype(np.float64)) ** 2).sum(1)
+    assert (np.abs(a[1][:, 0] - chk) <= 1e-5 * chk).all()
+    ix.close()
+    e.close()
