@@ -167,6 +167,22 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
     return mine;
 }
 
+// check_element_closer (graph/mod.rs:315-339): is any d(q, ids[j]) <= thr?  Rows are evaluated FUSED_RB at a time in list
+// order and the scan stops at the first batch that contains a hit, like the reference's early `return false`
+// (the answer is the same; fewer rows are streamed for rejected candidates).  *n_eval += rows evaluated.
+template <class OP>
+__device__ __forceinline__ bool f_any_le(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
+                                         unsigned long long &n_eval)
+{
+    for (uint32_t j0 = 0; j0 < n; j0 += FUSED_RB) {
+        const uint32_t nb = n - j0 < FUSED_RB ? n - j0 : FUSED_RB;
+        const float d = f_dist_batch<OP>(p, qv, ids + j0, nb, lane);
+        n_eval += nb;
+        if (__ballot(lane < nb && d <= thr) != 0ull) return true;
+    }
+    return false;
+}
+
 // Algorithm 2 with entry points EP[0..n_ep); leaves the result set in the W heap (cx.CTL[1] = |W|).
 // scan == false: search_layer (graph/mod.rs:161-255); scan == true: search_layer_disk without `discarded` (scan.rs:302-448).
 template <class OP>
@@ -389,9 +405,7 @@ k_fused(const FusedParams p)
                         if (r > 0) {
                             if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
                             f_park(p, p.rows + (size_t)e.y * p.pitch, lane, cx.EV);
-                            const float dj = f_dist_batch<OP>(p, cx.EV, cx.IDS, r, lane);
-                            cx.nd1 += r;
-                            closer = __ballot(lane < r && dj <= fh_d(e)) == 0ull;    // mod.rs:333-335 (any r rejects)
+                            closer = !f_any_le<OP>(p, cx.EV, cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
                             __syncthreads();
                         }
                         if (lane == 0) { if (closer) cx.RL[r] = e; else cx.DL[nd] = e; }

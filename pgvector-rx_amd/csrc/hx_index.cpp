@@ -576,8 +576,7 @@ struct hx_index {
         const uint32_t m = (uint32_t)g.m;
         int rc = e->mirror_reserve(m, g.size(), g.up.size() / m + 1);
         if (rc) return fail(rc, e->err);
-        std::sort(dirty.begin(), dirty.end());
-        dirty.erase(std::unique(dirty.begin(), dirty.end()), dirty.end());
+        // a list recorded twice is scattered twice with the same (current) content: harmless, and cheaper than sorting
         const uint32_t n_new = g.size() - mirror_elems, n_rec = (uint32_t)dirty.size();
         if (n_new == 0 && n_rec == 0) return HX_OK;
         std::vector<int32_t> lv(n_new); std::vector<uint32_t> blk(n_new);
