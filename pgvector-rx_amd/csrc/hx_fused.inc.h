@@ -19,6 +19,9 @@
 #include <cstdio>
 #define FUSED_MAXCH 8          /* 1 KiB chunks per row: pitch <= 8192 B covers vector(2000), halfvec(4000), bit(64000) */
 #define FUSED_RB 4             /* rows in flight per wave ... */
+#ifndef FUSED_MINW
+#define FUSED_MINW 4
+#endif
 #define FUSED_CG 3             /* ... times chunks of each requested at once */
 #define FUSED_CCAP 8192u       /* candidate-heap capacity per search (LDS head + global spill) */
 #define FUSED_MAXL 8           /* layers 0..7 handled on the device (P(level >= 8) = 16^-8 at m=16) */
@@ -308,7 +311,7 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
 }
 
 template <class OP, int MODE>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors)
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, FUSED_MINW)
 k_fused(const FusedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
