@@ -131,11 +131,14 @@ def main():
         ix.set_fused(False)
 
     # ---- build (timed once; barrier + sync on both sides; max over ranks) ----
+    dist_stages = None
     barrier()
     t0 = time.perf_counter()
     if world > 1:
         from importlib import import_module
-        import_module("pgvector-rx_amd.dist_build").insert_sharded(ix, 0, levels, a.batch, dist, xdev)
+        dbm = import_module("pgvector-rx_amd.dist_build")
+        dbm.insert_sharded(ix, 0, levels, a.batch, dist, xdev)
+        dist_stages = {k: round(v, 3) for k, v in dbm.STAGE_SECONDS.items()}
     else:
         ix.insert(0, levels, batch=a.batch)
     barrier()
@@ -303,6 +306,7 @@ def main():
         "build_kernels": build_kernels,
         "host_profile": {"build": {k: round(v, 2) for k, v in build_prof.items()}, "search_all_steps": {k: round(v, 3) for k, v in search_prof.items()}},
         "fused": ix.fused_stats(),
+        "dist_build_stage_seconds_rank0": dist_stages,
         "build_distance_evals": {"search": int(counters[1]), "select": int(counters[2]), "backlink": int(counters[3])},
     }
     print(json.dumps(out), flush=True)

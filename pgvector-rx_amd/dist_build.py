@@ -14,8 +14,17 @@ so the graph after every batch is bit-identical on all ranks and identical to th
 batch schedule.  The only data-path collectives are those two all_gathers per batch.  Batches smaller than
 `min_shard` members are built redundantly on every rank (a collective would cost more than it saves).
 """
+import time
+
 import numpy as np
 import torch
+
+STAGE_SECONDS = {}      # wall time per stage of the last insert_sharded call (rank-local, for bench.py's report)
+
+
+def _t(name, t0):
+    STAGE_SECONDS[name] = STAGE_SECONDS.get(name, 0.0) + time.perf_counter() - t0
+    return time.perf_counter()
 
 
 def slice_bounds(b, world):
@@ -57,28 +66,43 @@ def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_sh
     tids = np.arange(first_row, first_row + n, dtype=np.int64) if tids is None else np.ascontiguousarray(tids, np.int64)
     elems = np.empty(n, np.uint32)
     done = 0
+    STAGE_SECONDS.clear()
     while done < n:
         size = ix.size
         b = min(batch, n - done, max(1, size // 8))           # same ramp-up rule as hx_index_insert
         if ix.entry < 0 or b < min_shard or world == 1:
             # replicated: every rank performs the identical single-GPU step
+            t0 = time.perf_counter()
             elems[done:done + b] = ix.insert(first_row + done, levels[done:done + b], tids[done:done + b], batch=b)
+            _t("replicated_small_batches", t0)
             done += b
             continue
         lo, hi = slice_bounds(b, world)
+        t0 = time.perf_counter()
         ix.batch_begin(first_row + done, levels[done:done + b], tids[done:done + b])
+        t0 = _t("begin", t0)
         ix.batch_search(lo[rank], hi[rank])
+        t0 = _t("search", t0)
         sizes = [ix.batch_new_bytes(lo[r], hi[r]) for r in range(world)]
         mine = ix.batch_export_new(lo[rank], hi[rank])
-        for r, buf in enumerate(exchange(mine, sizes, rank, dist, device)):
+        t0 = _t("export_new", t0)
+        bufs = exchange(mine, sizes, rank, dist, device)
+        t0 = _t("allgather_new", t0)
+        for r, buf in enumerate(bufs):
             if r != rank and sizes[r]:
                 ix.batch_import_new(lo[r], hi[r], buf)
+        t0 = _t("import_new", t0)
         ix.batch_links(rank, world)
+        t0 = _t("links", t0)
         mine = ix.batch_export_links()
         sizes = gather_sizes(len(mine), dist, device)
-        for r, buf in enumerate(exchange(mine, sizes, rank, dist, device)):
+        t0 = _t("export_links", t0)
+        bufs = exchange(mine, sizes, rank, dist, device)
+        t0 = _t("allgather_links", t0)
+        for r, buf in enumerate(bufs):
             if r != rank and sizes[r]:
                 ix.batch_import_links(buf)
+        t0 = _t("import_links", t0)
         elems[done:done + b] = ix.batch_end(b)
         done += b
     return elems

@@ -69,6 +69,37 @@ CASES = [
 ]
 
 
+# placements the default sizes never reach: m = 20 (fused searches, back-links on the lock-step path because k_links
+# stops at m = 16), m = 40 (2m > 64: everything lock-step, select_neighbors in several blocks), ef_construction = 400,
+# and the widest rows each type allows in an index (8 000-byte pitch: 8 chunks per row)
+EDGE_CASES = [
+    (hx.F32, hx.L2SQ, 8, 500, 20, 48, 37),
+    (hx.F32, hx.NEG_IP, 12, 400, 40, 80, 29),
+    (hx.F32, hx.L2SQ, 6, 900, 16, 400, 64),
+    (hx.F32, hx.L1, 2000, 160, 4, 16, 16),
+    (hx.F16, hx.NEG_IP, 4000, 150, 4, 16, 16),
+    (hx.BIT, hx.HAMMING, 64000, 120, 4, 16, 16),
+]
+
+
+@pytest.mark.parametrize("dtype,metric,dim,n,m,efc,batch", EDGE_CASES)
+def test_graph_identical_edge_placements(dtype, metric, dim, n, m, efc, batch):
+    rng = np.random.default_rng(dim + m)
+    rows = make_rows(dtype, n, dim, rng)
+    levels = hx.draw_levels(n, m, seed=6)
+    e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, batch, True)
+    assert elem.tolist() == oelem.tolist()
+    assert_same_graph(ix, o, n)
+    qs = make_rows(dtype, 10, dim, rng)
+    e.set_queries(qs)
+    tids, d, el, cnt = ix.search(10, 40, 10)
+    for q in range(10):
+        want = o.scan(qs[q], ef_search=40, limit=10)
+        assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in want]
+    ix.close()
+    e.close()
+
+
 @pytest.mark.parametrize("dtype,metric,dim,n,m,efc", CASES)
 @pytest.mark.parametrize("batch", [1, 37])
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "lockstep"])
