@@ -49,10 +49,18 @@ __device__ __forceinline__ float fh_d(const uint2 &v) { return __builtin_bit_cas
 // Heap storage: the first `L` entries live in LDS, the rest in this workgroup's spill area in global memory (only lane 0
 // touches a heap, and a thread sees its own stores in program order).  Deep heaps are rare and only their bottom level
 // spills, so the common case never leaves LDS while the LDS budget per search stays small.
+typedef __attribute__((address_space(3))) uint2 lds_uint2;     // LDS-qualified: keeps heap accesses ds_read/ds_write, never FLAT
 struct HStore {
-    uint2 *lds, *glob; uint32_t L;
-    __device__ __forceinline__ uint2 get(uint32_t i) const { return i < L ? lds[i] : glob[i - L]; }
-    __device__ __forceinline__ void set(uint32_t i, uint2 v) const { if (i < L) lds[i] = v; else glob[i - L] = v; }
+    lds_uint2 *lds; uint2 *glob; uint32_t L;
+    __device__ __forceinline__ uint2 get(uint32_t i) const
+    {
+        if (i < L) return make_uint2(lds[i].x, lds[i].y);
+        return glob[i - L];
+    }
+    __device__ __forceinline__ void set(uint32_t i, uint2 v) const
+    {
+        if (i < L) { lds[i].x = v.x; lds[i].y = v.y; } else glob[i - L] = v;
+    }
 };
 
 // Rust std BinaryHeap; NEAREST: smallest distance on top.  Called by ONE lane.
@@ -329,8 +337,8 @@ k_fused(const FusedParams p)
     cx.QV = (uint8_t *)(cx.CTL + 16);                     // query parked in LDS (nch KiB)
     cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
-    cx.CH.lds = cx.C; cx.CH.glob = p.spill + (size_t)blockIdx.x * p.spill_stride; cx.CH.L = p.clds;
-    cx.WH.lds = cx.W; cx.WH.glob = nullptr; cx.WH.L = 0xffffffffu;
+    cx.CH.lds = (lds_uint2 *)cx.C; cx.CH.glob = p.spill + (size_t)blockIdx.x * p.spill_stride; cx.CH.L = p.clds;
+    cx.WH.lds = (lds_uint2 *)cx.W; cx.WH.glob = nullptr; cx.WH.L = 0xffffffffu;
     cx.lane = threadIdx.x;
     cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
     cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
