@@ -359,7 +359,7 @@ class Index:
         self._ck(lib().hx_index_profile(self.h, _p(p), int(reset)))
         return {"advance_s": p[0], "compact_s": p[1], "fill_s": p[2], "round_s": p[3], "rounds": int(p[5]), "fused_s": p[6],
                 "mirror_sync_s": p[7], "links_setup_s": p[8], "links_lockstep_s": p[9], "insert_total_s": p[10],
-                "batch_search_s": p[11], "batch_begin_s": p[12]}
+                "batch_search_s": p[11], "batch_begin_s": p[12], "links_max_chain": int(p[13]), "links_ops": int(p[14])}
 
     def set_fused(self, on):
         self._ck(lib().hx_index_set_fused(self.h, int(on)))

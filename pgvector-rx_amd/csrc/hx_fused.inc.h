@@ -733,7 +733,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     float *nd = ld2 + 40;                          // d(new row, slot j)
     uint32_t *pos = (uint32_t *)(nd + 40);         // sorted candidate k -> slot (LC_SLOTS = the new row)
     float *sd = (float *)(pos + 40);
-    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *IDS = dis + 40;   // IDS[64]
+    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *ORD = dis + 40, *IDS = ORD + 40;   // IDS[64]
     uint8_t *QV = (uint8_t *)(IDS + 64);
     const uint32_t lane = threadIdx.x;
     const uint32_t g = blockIdx.x;
@@ -771,16 +771,12 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
             __syncthreads();
         }
         v = cnt;
-        // the new row against every slot
-        if (lane < cnt) IDS[lane] = lid[lane];
-        f_park(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
-        {
-            const float d = f_dist_batch<OP>(fp, QV, IDS, cnt, lane);
-            if (lane < cnt) nd[lane] = d;
-            ndist += cnt;
-        }
+        // d(new row, slot) is evaluated LAZILY: a hub list (inner product on unnormalised rows sends thousands of back-links
+        // per batch to one list, all applied by this one wave in order) drops most newcomers after a few comparisons, so
+        // streaming all `cnt` neighbour rows per op would be a long serial chain of wasted loads.  Order of evaluation:
+        // the slots already accepted when the walk reaches the new row first (FUSED_RB at a time, stop at the first batch
+        // with a hit, like check_element_closer's early return), the remaining slots only if the new row stays in the list.
         const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
-        __syncthreads();
         if (lane < n) {
             const float d = lane < cnt ? ld[lane] : new_d; uint32_t rank = 0;
             for (uint32_t j = 0; j < n; j++) { const float dj = j < cnt ? ld[j] : new_d; rank += (dj < d) || (dj == d && j < lane); }
@@ -788,17 +784,56 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
         }
         __syncthreads();
         // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
-        uint32_t r = 0, ndc = 0;
+        uint32_t r = 0, ndc = 0, n_done = 0;      // n_done: how many entries of the evaluation order ORD have their nd[]
+        bool ordered = false; unsigned long long amask = 0ull;   // slots accepted so far
+        auto finish_nd = [&]() {                  // all remaining d(new, slot)
+            if (!ordered) {
+                if (lane < cnt) { IDS[lane] = lid[lane]; ORD[lane] = lane; }
+                f_park(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
+                ordered = true;
+            }
+            if (n_done < cnt) {
+                const float d = f_dist_batch<OP>(fp, QV, IDS + n_done, cnt - n_done, lane);
+                if (lane < cnt - n_done) nd[ORD[n_done + lane]] = d;
+                ndist += cnt - n_done; n_done = cnt;
+            }
+            __syncthreads();
+        };
         for (uint32_t i = 0; i < n; i++) {
             if (r >= lm) break;
             const float ed = sd[i]; const uint32_t si = pos[i];
-            bool hit = false;
-            if (lane < r) {
-                const uint32_t sj = pos[sel[lane]];
-                const float dij = si == LC_SLOTS ? nd[sj] : (sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)]);
-                hit = dij <= ed;                                                   // mod.rs:333-335
+            bool closer;
+            if (si == LC_SLOTS) {
+                // accepted slots first in the evaluation order
+                const bool acc = lane < cnt && ((amask >> lane) & 1ull) != 0ull;
+                const unsigned long long am = amask, below = (1ull << lane) - 1ull;
+                const uint32_t na = (uint32_t)__popcll(am);
+                if (lane < cnt) {
+                    const uint32_t o = acc ? (uint32_t)__popcll(am & below) : na + (uint32_t)__popcll(~am & below);
+                    IDS[o] = lid[lane]; ORD[o] = lane;
+                }
+                f_park(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
+                ordered = true;
+                bool hit = false;
+                for (uint32_t j0 = 0; j0 < na && !hit; j0 += FUSED_RB) {
+                    const uint32_t nb = na - j0 < FUSED_RB ? na - j0 : FUSED_RB;
+                    const float d = f_dist_batch<OP>(fp, QV, IDS + j0, nb, lane);
+                    if (lane < nb) nd[ORD[j0 + lane]] = d;
+                    ndist += nb; n_done = j0 + nb;
+                    hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
+                }
+                closer = !hit;
+                if (closer) finish_nd();                                           // later candidates are compared with the new row
+            } else {
+                bool hit = false;
+                if (lane < r) {
+                    const uint32_t sj = pos[sel[lane]];
+                    const float dij = sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)];
+                    hit = dij <= ed;                                               // mod.rs:333-335
+                }
+                closer = __ballot(hit) == 0ull;
+                if (closer) amask |= 1ull << si;
             }
-            const bool closer = __ballot(hit) == 0ull;
             if (lane == 0) { if (closer) sel[r] = i; else dis[ndc] = i; }
             if (closer) r++; else ndc++;
             __syncthreads();
@@ -806,6 +841,10 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
         if (lane == 0) for (uint32_t j = 0; j < ndc && r < lm; j++) sel[r++] = dis[j];   // mod.rs:300-305
         r = __shfl(r, 0, 64);
         __syncthreads();
+        {   // the new row's distances to every slot are needed only if it stays in the list
+            bool mine = lane < r && pos[sel[lane]] == LC_SLOTS;
+            if (__ballot(mine) != 0ull) finish_nd();
+        }
         // surviving list and its pair matrix
         if (lane < r) { const uint32_t sa = pos[sel[lane]]; lid2[lane] = sa == LC_SLOTS ? new_id : lid[sa]; ld2[lane] = sd[sel[lane]]; }
         for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) {
@@ -835,7 +874,7 @@ template <class OP>
 static hipError_t launch_links_cached(hx_engine *e, const LinksParams &p)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
-    const size_t lds = (528 * 2 + 40 * 10 + 64) * 4 + nch * 1024;
+    const size_t lds = (528 * 2 + 40 * 11 + 64) * 4 + nch * 1024;
     hipLaunchKernelGGL((k_links_cached<OP>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
     return hipGetLastError();
 }

@@ -946,6 +946,8 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         const uint32_t ng = (uint32_t)own.size(), lm0 = 2u * (uint32_t)g.m;
         std::vector<uint32_t> tg(ng), ly(ng), off(ng + 1, 0u);
         for (uint32_t k = 0; k < ng; k++) off[k + 1] = off[k] + (uint32_t)(bs.grp[own[k]].second - bs.grp[own[k]].first);
+        for (uint32_t k = 0; k < ng; k++) ix->prof[13] = std::max(ix->prof[13], (double)(off[k + 1] - off[k]));   // longest serial op chain of one list
+        ix->prof[14] += off[ng];
         std::vector<uint32_t> onew(off[ng]); std::vector<float> od(off[ng]);
         ix->pool->parallel_for((ng + 4095) / 4096, [&](size_t ci) {
             for (size_t k = ci * 4096; k < std::min<size_t>(ng, ci * 4096 + 4096); k++) {

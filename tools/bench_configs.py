@@ -1,0 +1,151 @@
+"""The other BASELINE.json configs at single-GPU sizes (bench.py is the contract bench for configs[1]).
+
+    python tools/bench_configs.py c1|c3|c4|c5 [rows]
+
+c1: 10k x vector(128) L2, m16 efc64 efs40                      (configs[0], also what the CPU oracle can run in full)
+c3: N x vector(1536) cosine (N(0,1) rows, f64-normalised on the device), m16 efc200      (configs[2] shape, 1 GPU)
+c4: N x halfvec(4000) inner product (2*U*U rounded to f16), m16 efc200                   (configs[3] shape, 1 GPU)
+c5: N x bit(1024) Hamming, plain scan + iterative_scan=relaxed_order with a 1 % filter, max_scan_tuples=20000 (configs[4] shape)
+Prints one JSON line: build seconds, QPS, recall@10 vs exact brute force (torch), kernel roofline figures.
+"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import pgvector_rx_amd as hx  # noqa: E402
+
+DEV = "cuda"
+
+
+def recall(tids, cnt, gt, k):
+    return sum(len(set(tids[q, :cnt[q]].tolist()) & set(gt[q].tolist())) for q in range(gt.shape[0])) / (gt.shape[0] * k)
+
+
+def topk_chunks(score_fn, nq, n_rows, k, largest):
+    out = []
+    step = max(1, int(1.5e9 // (n_rows * 4)))
+    for i in range(0, nq, step):
+        s = score_fn(i, min(nq, i + step))
+        out.append(torch.topk(s, k, dim=1, largest=largest).indices)
+    return torch.cat(out).cpu().numpy()
+
+
+def clustered(g, n, dim, centers, sigma):
+    c = torch.randn((centers, dim), generator=g, device=DEV)
+    out = torch.empty((n, dim), device=DEV)
+    for i in range(0, n, 1 << 18):
+        j = min(n, i + (1 << 18))
+        out[i:j] = c[torch.randint(0, centers, (j - i,), generator=g, device=DEV)] + sigma * torch.randn((j - i, dim), generator=g, device=DEV)
+    return out
+
+
+def run(name, n, data="baseline"):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    k, nq, batch = 10, 10_000, 8192
+    iterative = None
+    if name == "c1":
+        n = n or 10_000
+        dim, m, efc, efs, dt, mt, nq = 128, 16, 64, 40, hx.F32, hx.L2SQ, 1000
+        rows = torch.rand((n, dim), generator=g, device=DEV)
+        qs = torch.rand((nq, dim), generator=g, device=DEV)
+        gt_fn = lambda: topk_chunks(lambda a, b: (rows * rows).sum(1)[None, :] - 2.0 * qs[a:b] @ rows.T, nq, n, k, False)
+        normalize = False
+    elif name == "c3":
+        n = n or 1_000_000
+        dim, m, efc, efs, dt, mt = 1536, 16, 200, 100, hx.F32, hx.NEG_IP
+        if data == "clustered":
+            both = clustered(g, n + nq, dim, 2000, 0.6)
+            rows, qs = both[:n].contiguous(), both[n:].contiguous()
+        else:
+            rows = torch.randn((n, dim), generator=g, device=DEV)
+            qs = torch.randn((nq, dim), generator=g, device=DEV)
+        normalize = True
+        gt_fn = None       # set after normalisation (cosine == -IP on unit vectors, vector.rs:852-856)
+    elif name == "c4":
+        n = n or 500_000
+        dim, m, efc, efs, dt, mt = 4000, 16, 200, 100, hx.F16, hx.NEG_IP
+        rows = (2.0 * torch.rand((n, dim), generator=g, device=DEV) * torch.rand((n, dim), generator=g, device=DEV)).to(torch.float16)
+        qs = (2.0 * torch.rand((nq, dim), generator=g, device=DEV) * torch.rand((nq, dim), generator=g, device=DEV)).to(torch.float16)
+        normalize = False
+        gt_fn = lambda: topk_chunks(lambda a, b: qs[a:b].float() @ rows.float().T if n <= 200_000 else (qs[a:b] @ rows.T).float(), nq, n, k, True)
+    elif name == "c5":
+        n = n or 2_000_000
+        dim, m, efc, efs, dt, mt, nq = 1024, 16, 64, 40, hx.BIT, hx.HAMMING, 2000
+        rows = torch.randint(0, 256, (n, dim // 8), generator=g, device=DEV, dtype=torch.uint8)
+        qs = torch.randint(0, 256, (nq, dim // 8), generator=g, device=DEV, dtype=torch.uint8)
+        if data == "clustered":        # 4096 random centre patterns, every bit flipped with probability 1/8 (AND of three random bytes)
+            cen = torch.randint(0, 256, (4096, dim // 8), generator=g, device=DEV, dtype=torch.uint8)
+            def noisy(x):
+                f = x.clone()
+                for _ in range(2):
+                    f &= torch.randint(0, 256, x.shape, generator=g, device=DEV, dtype=torch.uint8)
+                return cen[torch.randint(0, 4096, (x.shape[0],), generator=g, device=DEV)] ^ f
+            rows, qs = noisy(rows), noisy(qs)
+        normalize = False
+        iterative = {"mode": 1, "max_scan_tuples": 20000, "limit": 10, "filter_every": 100}
+
+        def bits_pm1(x):
+            sh = torch.arange(7, -1, -1, device=DEV, dtype=torch.uint8)
+            return (((x[:, :, None] >> sh) & 1).reshape(x.shape[0], -1).to(torch.float16) * 2 - 1)
+        rpm = bits_pm1(rows)
+        gt_fn = lambda: topk_chunks(lambda a, b: (bits_pm1(qs[a:b]) @ rpm.T).float(), nq, n, k, True)   # larger dot = smaller Hamming
+    else:
+        raise SystemExit(__doc__)
+    torch.cuda.synchronize()
+    eng = hx.Engine(dt, mt, dim, n)
+    eng.append_device(rows.data_ptr(), n)
+    skipped = 0
+    if normalize:
+        norms = eng.normalize_rows(0, n)
+        skipped = int((norms == 0).sum())
+        rown = torch.from_numpy(eng.read_rows(0, n)).to(DEV) if n <= 200_000 else torch.nn.functional.normalize(rows.double(), dim=1).float()
+        gt_fn = lambda: topk_chunks(lambda a, b: qs[a:b] @ rown.T, nq, n, k, True)
+    levels = hx.draw_levels(n, m, seed=21)
+    ix = hx.Index(eng, m, efc)
+    eng.set_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ix.insert(0, levels, batch=batch)
+    build = time.perf_counter() - t0
+    bstats = {"fused_insert": eng.kernel_stats(2, reset=True), "links": eng.kernel_stats(3, reset=True)}
+    eng.set_queries_device(qs.data_ptr(), nq, normalize=normalize)
+    ix.search(nq, efs, k)
+    eng.kernel_stats(2, reset=True)
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tids, d, _, cnt = ix.search(nq, efs, k)
+    dt_s = time.perf_counter() - t0
+    fq = eng.kernel_stats(2)
+    gt = gt_fn()
+    row_bytes = eng.row_bytes
+    out = {"config": name, "data": data, "rows": n, "dim": dim, "dtype": {0: "f32", 1: "f16", 2: "bit"}[dt], "metric": {0: "l2", 1: "neg_ip", 3: "hamming"}[mt],
+           "m": m, "ef_construction": efc, "ef_search": efs, "build_sec": round(build, 2), "rows_skipped_zero_norm": skipped,
+           "qps": round(nq * steps / dt_s, 1), "queries_per_step": nq, "recall_at_10": round(recall(tids, cnt, gt, k), 4),
+           "k_fused_query_GBps": round(fq["units"] * row_bytes / max(fq["ms"], 1e-9) / 1e6, 1),
+           "k_fused_insert_GBps": round(bstats["fused_insert"]["units"] * row_bytes / max(bstats["fused_insert"]["ms"], 1e-9) / 1e6, 1),
+           "k_fused_insert_ms": round(bstats["fused_insert"]["ms"], 1), "k_links_ms": round(bstats["links"]["ms"], 1),
+           "fused": ix.fused_stats(), "host_profile": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ix.profile().items()}}
+    if iterative:
+        passes = (np.arange(n) % iterative["filter_every"] == 0).astype(np.uint8)
+        nqi = 500
+        t0 = time.perf_counter()
+        it_tids, it_d, it_cnt = ix.search_iterative(nqi, efs, iterative["mode"], iterative["max_scan_tuples"], iterative["limit"], passes)
+        it_s = time.perf_counter() - t0
+        # exact answer under the filter
+        sub = torch.nonzero(torch.from_numpy(passes).to(DEV)).squeeze(1)
+        sc = (bits_pm1(qs[:nqi]) @ rpm[sub].T).float()
+        gti = sub[torch.topk(sc, k, dim=1).indices].cpu().numpy()
+        out["iterative_relaxed"] = {"queries": nqi, "filter": "tid %% %d == 0" % iterative["filter_every"], "max_scan_tuples": iterative["max_scan_tuples"],
+                                    "qps": round(nqi / it_s, 1), "recall_at_10": round(recall(it_tids, it_cnt, gti, k), 4),
+                                    "mean_returned": float(it_cnt.mean()), "path": "lock-step host driver (discarded heap)"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    run(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0, sys.argv[3] if len(sys.argv) > 3 else "baseline")
