@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libhnswrx.so")
+LIB = os.environ.get("HX_LIB") or os.path.join(HERE, "libhnswrx.so")   # HX_LIB: load a prebuilt variant as is (kernel tuning experiments)
 SOURCES = ["hx_engine.hip", "hx_index.cpp"]
 HEADERS = ["hx_internal.h", os.path.join("..", "..", "include", "hnswrx.h")]
 # -ffp-contract=off: mul and add are rounded separately, as in the reference's unfused Rust
@@ -26,7 +26,7 @@ def stale():
 
 
 def build(force=False, verbose=False):
-    if not force and not stale():
+    if os.environ.get("HX_LIB") or (not force and not stale()):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB, "-lpthread"]

@@ -37,20 +37,40 @@ __device__ __forceinline__ float half2f(unsigned int h16)
     return (float)__builtin_bit_cast(_Float16, (unsigned short)h16);
 }
 
-template <int LPR> __device__ __forceinline__ float lanes_sum_f(float v)
+// xor-butterfly exchange v[lane ^ OFF] without touching LDS: __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round
+// trip, ~100+ cycles each, six in a row per reduced value -- measured as half of a row batch's time in the traversal
+// kernel).  gfx950 has the half/row swaps as VALU ops, and the steps inside a 16-lane row are DPP moves:
+//   32: v_permlane32_swap(v, v) leaves {lo,lo} and {hi,hi}; 16: v_permlane16_swap likewise on row pairs;
+//   8 = row_half_mirror . row_mirror, 4 = quad_perm[3,2,1,0] . row_half_mirror, 2 / 1 = quad_perm.
+// The sums are the butterfly's own (a + b is the same value in both partners), so the canonical order is unchanged.
+template <int CTRL> __device__ __forceinline__ unsigned int dpp_mov(unsigned int v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-        if (off < LPR) v = v + __shfl_xor(v, off, 64);
-    return v;
+    return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
 }
-template <int LPR> __device__ __forceinline__ int lanes_sum_i(int v)
+template <int OFF> __device__ __forceinline__ void xor_pair(unsigned int v, unsigned int &a, unsigned int &b)
+{   // a (+) b == v[lane] (+) v[lane ^ OFF] for a commutative (+)
+    if constexpr (OFF == 32) { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); a = r[0]; b = r[1]; }
+    else if constexpr (OFF == 16) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); a = r[0]; b = r[1]; }
+    else if constexpr (OFF == 8) { a = v; b = dpp_mov<0x141>(dpp_mov<0x140>(v)); }
+    else if constexpr (OFF == 4) { a = v; b = dpp_mov<0x1B>(dpp_mov<0x141>(v)); }
+    else if constexpr (OFF == 2) { a = v; b = dpp_mov<0x4E>(v); }
+    else { a = v; b = dpp_mov<0xB1>(v); }
+}
+template <int LPR, int OFF> __device__ __forceinline__ float lanes_sum_f_step(float v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1)
-        if (off < LPR) v = v + __shfl_xor(v, off, 64);
-    return v;
+    if constexpr (OFF < LPR) {
+        unsigned int a, b; xor_pair<OFF>(__builtin_bit_cast(unsigned int, v), a, b);
+        v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    }
+    if constexpr (OFF > 1) return lanes_sum_f_step<LPR, OFF / 2>(v); else return v;
 }
+template <int LPR, int OFF> __device__ __forceinline__ int lanes_sum_i_step(int v)
+{
+    if constexpr (OFF < LPR) { unsigned int a, b; xor_pair<OFF>((unsigned int)v, a, b); v = (int)a + (int)b; }
+    if constexpr (OFF > 1) return lanes_sum_i_step<LPR, OFF / 2>(v); else return v;
+}
+template <int LPR> __device__ __forceinline__ float lanes_sum_f(float v) { return lanes_sum_f_step<LPR, 32>(v); }
+template <int LPR> __device__ __forceinline__ int lanes_sum_i(int v) { return lanes_sum_i_step<LPR, 32>(v); }
 
 // ---- per-(dtype, metric) operators: add() consumes one 16-byte fragment pair, finish() reduces ----
 enum { K_L2 = 0, K_IP = 1, K_L1 = 2 };

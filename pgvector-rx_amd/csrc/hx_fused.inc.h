@@ -18,7 +18,9 @@
 
 #include <cstdio>
 #define FUSED_MAXCH 8          /* 1 KiB chunks per row: pitch <= 8192 B covers vector(2000), halfvec(4000), bit(64000) */
+#ifndef FUSED_RB
 #define FUSED_RB 4             /* rows in flight per wave ... */
+#endif
 #ifndef FUSED_MINW
 #define FUSED_MINW 4
 #endif
@@ -100,27 +102,111 @@ template <bool NEAREST> struct FHeap {
     }
 };
 
-// visited set (HashSet<usize> of graph/mod.rs:171): a per-workgroup open-addressing table of row ids in global memory,
-// small enough (32-64 KB) to stay in L2 / Infinity Cache however large the index is.  Lanes insert concurrently with
-// atomicCAS; returns true if the id was already present.
+// The same Rust std BinaryHeap, executed by the WHOLE wavefront on an LDS array (every lane calls with identical
+// arguments and gets identical results).  Serial heap code is what a GPU is worst at -- measured 3 us per pop, a third of
+// an expansion step -- but the heap's moves are more parallel than they look:
+//   * sift_up's path (the ancestors of the new slot) is known up front: lane k reads ancestor k, one ballot finds where
+//     the walk stops, and the lanes below shift their ancestors down in one store;
+//   * sift_down_to_bottom's path depends only on the heap's contents, never on the moving element: it is a pointer
+//     chase of one LDS read (both children) per level with lane k latching level k; the closing sift_up along that
+//     same path is again one ballot, and all the moves are one store.
+// The resulting array is the one the serial algorithm leaves, element for element (ties included).
+#define F_WSYNC() asm volatile("" ::: "memory")     /* LDS ops of one wave execute in order; only the compiler must not reorder */
+template <bool NEAREST> struct PHeap {
+    static __device__ __forceinline__ bool le(float a, float b) { return NEAREST ? !(b > a) : !(a > b); }
+    static __device__ __forceinline__ uint2 ld(lds_uint2 *A, uint32_t i) { return make_uint2(A[i].x, A[i].y); }
+    static __device__ __forceinline__ void st(lds_uint2 *A, uint32_t i, uint2 v) { A[i].x = v.x; A[i].y = v.y; }
+    static __device__ __forceinline__ void push(lds_uint2 *A, uint32_t &len, uint2 c, uint32_t lane)
+    {
+        F_WSYNC();
+        const uint32_t pos1 = len + 1u; len++;                         // 1-based slot of the new element
+        const uint32_t depth = 31u - (uint32_t)__builtin_clz(pos1);    // number of ancestors
+        const bool anc = lane >= 1u && lane <= depth;                  // lane k holds the k-th ancestor
+        uint2 v = make_uint2(0u, 0u);
+        if (anc) v = ld(A, (pos1 >> lane) - 1u);
+        const unsigned long long sm = __ballot(anc && le(fh_d(c), fh_d(v)));   // sift_up breaks at the first such ancestor
+        const uint32_t t = sm ? (uint32_t)__builtin_ctzll(sm) : depth + 1u;
+        if (anc && lane < t) st(A, (pos1 >> (lane - 1u)) - 1u, v);     // ancestors below the stop move down one level
+        if (lane == 0u) st(A, (pos1 >> (t - 1u)) - 1u, c);
+        F_WSYNC();
+    }
+    static __device__ __forceinline__ uint2 pop(lds_uint2 *A, uint32_t &len, uint32_t lane)   // len > 0
+    {
+        F_WSYNC();
+        const uint2 last = ld(A, len - 1u); len--;
+        if (len == 0u) return last;
+        const uint2 top = ld(A, 0u);
+        const uint32_t end = len;
+        uint32_t pos = 0u, child = 1u, k = 0u;
+        uint32_t myP = 0u, myC = 0u; uint2 myV = make_uint2(0u, 0u);   // lane k: path slot k, path slot k+1 and its old value
+        while (end >= 2u && child <= end - 2u) {
+            const uint2 a = ld(A, child), b = ld(A, child + 1u);
+            const bool right = le(fh_d(a), fh_d(b));
+            const uint2 cv = right ? b : a; const uint32_t cp = child + (right ? 1u : 0u);
+            if (lane == k) { myP = pos; myC = cp; myV = cv; }
+            pos = cp; child = 2u * pos + 1u; k++;
+        }
+        if (child == end - 1u) {
+            const uint2 a = ld(A, child);
+            if (lane == k) { myP = pos; myC = child; myV = a; }
+            k++;
+        }
+        // the moved element climbs back from the bottom of the path while it beats its parent: it ends in path slot t
+        const unsigned long long sm = __ballot(lane < k && le(fh_d(last), fh_d(myV)));
+        const uint32_t t = sm ? 64u - (uint32_t)__builtin_clzll(sm) : 0u;
+        if (lane < t) st(A, myP, myV);
+        if (t == 0u) { if (lane == 0u) st(A, 0u, last); }
+        else if (lane == t - 1u) st(A, myC, last);
+        F_WSYNC();
+        return top;
+    }
+};
+
+// visited set (HashSet<usize> of graph/mod.rs:171): a per-workgroup open-addressing table of row ids in global memory
+// (32-64 KB per wave), organised as 16-byte BUCKETS of four ids.  A membership test is ONE 16-byte load (bypassing the
+// vector L1, because inserts are L2 atomics) of the key's bucket: the key is there, or the bucket still has an empty
+// slot (=> the key is absent: buckets only ever fill up, slots x,y,z,w in order), or -- rarely -- the bucket is full and
+// the next one is probed.  An insert is an atomicCAS on the first empty slot; its result is needed only to detect that
+// another lane of the same instruction took the slot, so the caller may look at it later (after the row loads of the
+// expansion have been issued) and re-insert then: the test costs one memory hop instead of one per probe.
 #define VIS_EMPTY 0xffffffffu
 __device__ __forceinline__ uint32_t vis_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
-__device__ __forceinline__ bool vis_test_and_set(uint32_t *tab, uint32_t mask, uint32_t key)
+// true: key present.  false: *slot = the empty slot the key belongs in
+__device__ __forceinline__ bool vis_lookup(uint32_t *tab, uint32_t bmask, uint32_t key, uint32_t *&slot)
 {
-    uint32_t h = vis_mix(key) & mask;
+    uint32_t b = vis_mix(key) & bmask;
     for (;;) {
-        const uint32_t old = atomicCAS(&tab[h], VIS_EMPTY, key);
-        if (old == VIS_EMPTY) return false;
-        if (old == key) return true;
-        h = (h + 1u) & mask;
+        const unsigned long long *bp = (const unsigned long long *)(tab + 4u * b);
+        const unsigned long long lo = __hip_atomic_load(bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t x = (uint32_t)lo, y = (uint32_t)(lo >> 32), z = (uint32_t)hi, w = (uint32_t)(hi >> 32);
+        if (x == key || y == key || z == key || w == key) return true;
+        const int e = x == VIS_EMPTY ? 0 : (y == VIS_EMPTY ? 1 : (z == VIS_EMPTY ? 2 : (w == VIS_EMPTY ? 3 : -1)));
+        if (e >= 0) { slot = tab + 4u * b + (uint32_t)e; return false; }
+        b = (b + 1u) & bmask;
     }
+}
+// deferred half of an insert: `old` is what the atomicCAS on `slot` returned; re-insert while another lane won the slot
+__device__ __forceinline__ void vis_settle(uint32_t *tab, uint32_t bmask, uint32_t key, uint32_t *slot, uint32_t old)
+{
+    while (old != VIS_EMPTY) {
+        (void)vis_lookup(tab, bmask, key, slot);
+        old = atomicCAS(slot, VIS_EMPTY, key);
+    }
+}
+__device__ __forceinline__ bool vis_test_and_set(uint32_t *tab, uint32_t bmask, uint32_t key)
+{
+    uint32_t *slot = nullptr;
+    if (vis_lookup(tab, bmask, key, slot)) return true;
+    vis_settle(tab, bmask, key, slot, atomicCAS(slot, VIS_EMPTY, key));
+    return false;
 }
 
 struct FusedCtx {
     uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
     unsigned long long nd0, nd1; uint32_t cmax;
-    unsigned long long tph[5];   // diagnostic phase clocks (HX_F_DBG & 4): pop, list+visited, distances, replay, other
+    uint32_t tph[13];  // diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
 };
 
 // parks one vector (row or query slot) in LDS, chunk-major: bytes [c*1024 + 16*lane, +16); zero past the pitch
@@ -139,9 +225,11 @@ __device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src,
 // FUSED_RB rows x FUSED_CG 1-KiB chunks are requested at once (one HBM latency per row batch at d <= 768 f32), then
 // consumed chunk by chunk in ascending order -- the canonical per-lane order.
 template <class OP>
-__device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
+__device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
     float mine = 0.0f;
+    unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
+#define FD_TICK(k) do { if (tk) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[k] += (uint32_t)(t_ - tq); tq = t_; } } while (0)
     const uint32_t loff = lane * 16u;
     for (uint32_t j0 = 0; j0 < n; j0 += FUSED_RB) {
         const uint8_t *rp[FUSED_RB];
@@ -160,6 +248,9 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
 #pragma unroll
                 for (int r = 0; r < FUSED_RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (in) v = *(const u4 *)(rp[r] + off); rv[r][k] = v; }
             }
+            FD_TICK(9);                                   // addresses + load issue
+            if (tk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FD_TICK(10);                                  // waiting for the rows
 #pragma unroll
             for (int k = 0; k < FUSED_CG; k++) {
                 if (c0 + k < p.nch) {
@@ -168,14 +259,18 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
                     for (int r = 0; r < FUSED_RB; r++) OP::add(acc[r], q, rv[r][k]);
                 }
             }
+            if (tk) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            FD_TICK(11);                                  // arithmetic
         }
 #pragma unroll
         for (int r = 0; r < FUSED_RB; r++) {
             const float d = OP::template finish<64>(acc[r]);
             if (j0 + r < n && lane == j0 + r) mine = d;
         }
+        FD_TICK(12);                                      // reductions
     }
     return mine;
+#undef FD_TICK
 }
 
 // check_element_closer (graph/mod.rs:315-339): is any d(q, ids[j]) <= thr?  Rows are evaluated FUSED_RB at a time in list
@@ -196,6 +291,7 @@ __device__ __forceinline__ bool f_any_le(const FusedParams &p, const uint8_t *qv
 
 // Algorithm 2 with entry points EP[0..n_ep); leaves the result set in the W heap (cx.CTL[1] = |W|).
 // scan == false: search_layer (graph/mod.rs:161-255); scan == true: search_layer_disk without `discarded` (scan.rs:302-448).
+#define F_TICK(k) do { if (tm) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); cx.tph[k] += (uint32_t)(t1_ - t0); t0 = t1_; } } while (0)
 template <class OP>
 __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan)
 {
@@ -204,39 +300,47 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
     uint32_t vcount = n_ep;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)p.vis_words - 1u, cx.EP[i].y);
-    if (lane == 0) {
-        uint32_t clen = 0, wlen = 0;
-        for (uint32_t i = 0; i < n_ep; i++) {
-            if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
-            FHeap<true>::push(cx.CH, clen, cx.EP[i]); FHeap<false>::push(cx.WH, wlen, cx.EP[i]);
-        }
-        cx.CTL[0] = clen; cx.CTL[1] = wlen; cx.CTL[2] = wlen;     // C len, W len, result_len
+    for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(p.vis_words >> 2) - 1u, cx.EP[i].y);
+    // heaps are driven by the whole wave (PHeap) while the candidate heap fits its LDS part; a heap that outgrows it
+    // (rare) is handed to the serial hybrid LDS+spill code on lane 0.  clen/wl/rlen: |C|, |W|, result_len -- wave-uniform.
+    uint32_t clen = 0, wl = 0, rlen = 0;
+    lds_uint2 *const CA = cx.CH.lds, *const WA = cx.WH.lds;
+    auto c_push = [&](uint2 it) {
+        if (clen < cx.CH.L) PHeap<true>::push(CA, clen, it, lane);
+        else { __syncthreads(); if (lane == 0) { uint32_t l = clen; FHeap<true>::push(cx.CH, l, it); } clen++; __syncthreads(); }
+    };
+    auto c_pop = [&]() -> uint2 {
+        if (clen <= cx.CH.L) return PHeap<true>::pop(CA, clen, lane);
+        __syncthreads();
+        if (lane == 0) { uint32_t l = clen; const uint2 c = FHeap<true>::pop(cx.CH, l); cx.RES[0] = c; }
+        clen--; __syncthreads();
+        const uint2 c = cx.RES[0]; __syncthreads();
+        return c;
+    };
+    for (uint32_t i = 0; i < n_ep; i++) {
+        if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
+        const uint2 it = cx.EP[i];
+        c_push(it); PHeap<false>::push(WA, wl, it, lane);
     }
+    rlen = wl;
     __syncthreads();
-    cx.status = __shfl(cx.status, 0, 64);
     for (;;) {
         if (cx.status != FS_OK) break;
-        // pop the nearest candidate (lane 0), decide whether to stop
+        // pop the nearest candidate, decide whether to stop
         const bool tm = (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (lane == 0) {
-            uint32_t clen = cx.CTL[0]; const uint32_t wl = cx.CTL[1];
-            uint32_t go = 0, cid = 0;
-            if (clen > 0) {
-                const uint2 c = FHeap<true>::pop(cx.CH, clen);
-                const float cd = fh_d(c);
-                bool stop;
-                if (!scan) { const float f = wl ? fh_d(cx.W[0]) : 3.402823466e+38f; stop = cd > f; }                     // mod.rs:188-193
-                else { const double f = wl ? (double)fh_d(cx.W[0]) : 1.7976931348623157e+308; stop = (double)cd > f; }    // scan.rs:339-346
-                if (!stop) { go = 1; cid = c.y; }
-            }
-            cx.CTL[0] = clen; cx.CTL[3] = go; cx.CTL[4] = cid;
+        uint32_t go = 0, cid = 0;
+        if (clen > 0) {
+            const uint2 c = c_pop();
+            const float cd = fh_d(c);
+            bool stop;
+            if (!scan) { const float f = wl ? __builtin_bit_cast(float, (unsigned int)WA[0].x) : 3.402823466e+38f; stop = cd > f; }                     // mod.rs:188-193
+            else { const double f = wl ? (double)__builtin_bit_cast(float, (unsigned int)WA[0].x) : 1.7976931348623157e+308; stop = (double)cd > f; }    // scan.rs:339-346
+            if (!stop) { go = 1; cid = c.y; }
         }
-        __syncthreads();
-        const uint32_t go = cx.CTL[3], cid = cx.CTL[4];
-        __syncthreads();
-        if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[0] += t1 - t0; t0 = t1; }
+        go = __builtin_amdgcn_readfirstlane(go); cid = __builtin_amdgcn_readfirstlane(cid);
+        F_TICK(0);
         if (!go) break;
+        if (tm) cx.tph[7]++;
         // a linked element at layer 0 always has level >= 0, so the check of mod.rs:198-200 needs no load there
         if (layer > 0 && p.level[cid] < layer) continue;
         const uint32_t *nb; uint32_t n, lmax;
@@ -244,61 +348,65 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         else { nb = p.up_ids + (size_t)(p.up_block[cid] + (uint32_t)(layer - 1)) * p.m; lmax = p.m; }
         const uint32_t e_first = lane < lmax ? nb[lane] : 0u;                        // issued together with the count: one memory hop
         if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
+        F_TICK(1);
         for (uint32_t n0 = 0; n0 < n; n0 += 64) {                                    // lists longer than a wave (m > 32) go in order
             const uint32_t idx = n0 + lane;
             uint32_t e = 0; bool unvis = false;
+            const uint32_t bmask = (uint32_t)(p.vis_words >> 2) - 1u;
+            uint32_t *vslot = nullptr; uint32_t vold = VIS_EMPTY;                    // insert in flight (settled below)
             if (idx < n) {
                 e = n0 == 0 ? e_first : nb[idx];
-                unvis = !vis_test_and_set(cx.vis, (uint32_t)p.vis_words - 1u, e);    // visited.contains / insert, mod.rs:206-209
+                unvis = !vis_lookup(cx.vis, bmask, e, vslot);                        // visited.contains / insert, mod.rs:206-209
+                if (unvis) vold = atomicCAS(vslot, VIS_EMPTY, e);
                 if (unvis && layer > 0 && p.level[e] < layer) unvis = false;         // mod.rs:213-216
             }
+            F_TICK(2);
             const unsigned long long mask = __ballot(unvis);
             const uint32_t cnt = (uint32_t)__popcll(mask);
             vcount += cnt;
             if (vcount * 4u > (uint32_t)p.vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
-            if (cnt == 0) continue;
+            if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
             __syncthreads();
-            if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[1] += t1 - t0; t0 = t1; }
-            const float mine = f_dist_batch<OP>(p, cx.QV, cx.IDS, cnt, lane);
+            F_TICK(3);
+            const float mine = f_dist_batch<OP>(p, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
+            F_TICK(4);
+            vis_settle(cx.vis, bmask, e, vslot, vold);                               // the CAS results came back with the rows
             if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
             cx.nd0 += cnt;
             // Pre-filter in parallel: once W is full (result_len >= ef) its furthest distance f only shrinks while this
             // list is replayed, so a row with d >= f NOW can never be added later in the replay; lane 0 then visits only the
             // survivors, in list order, and re-tests each against the current f -- same pushes, same order, as mod.rs:226-243.
-            const uint32_t wl0 = cx.CTL[1], rlen0 = cx.CTL[2];
             bool keep = lane < cnt;
-            if (keep && rlen0 >= ef && wl0 && !(p.fdbg & 1u)) {
-                const float f0 = fh_d(cx.W[0]);
+            if (keep && rlen >= ef && wl && !(p.fdbg & 1u)) {
+                const float f0 = __builtin_bit_cast(float, (unsigned int)WA[0].x);
                 keep = scan ? !((double)mine >= (double)f0) : (mine < f0);
             }
-            const unsigned long long kmask = __ballot(keep);
-            if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[2] += t1 - t0; t0 = t1; }
+            unsigned long long km = __ballot(keep);
+            F_TICK(5);
             __syncthreads();
-            if (lane == 0) {                                                         // replay in list order, mod.rs:226-243 / scan.rs:372-429
-                uint32_t clen = cx.CTL[0], wl = cx.CTL[1], rlen = cx.CTL[2];
-                unsigned long long km = kmask;
-                while (km) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(km); km &= km - 1ull;
-                    const uint2 it = cx.RES[j]; const float d = fh_d(it);
-                    const bool always_add = rlen < ef;
-                    bool add;
-                    if (!scan) { const float f = wl ? fh_d(cx.W[0]) : 3.402823466e+38f; add = d < f || always_add; }
-                    else { const double f = wl ? (double)fh_d(cx.W[0]) : 1.7976931348623157e+308; add = !(!always_add && (double)d >= f); }
-                    if (!add) continue;
-                    if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
-                    FHeap<true>::push(cx.CH, clen, it); FHeap<false>::push(cx.WH, wl, it); rlen++;
-                    if (clen > cx.cmax) cx.cmax = clen;
-                    if (rlen > ef) { (void)FHeap<false>::pop(cx.WH, wl); rlen--; }
-                }
-                cx.CTL[0] = clen; cx.CTL[1] = wl; cx.CTL[2] = rlen;
+            while (km) {                                                             // replay in list order, mod.rs:226-243 / scan.rs:372-429
+                const uint32_t j = (uint32_t)__builtin_ctzll(km); km &= km - 1ull;
+                const uint2 it = cx.RES[j]; const float d = fh_d(it);
+                const bool always_add = rlen < ef;
+                const float wtop = wl ? __builtin_bit_cast(float, (unsigned int)WA[0].x) : 0.0f;
+                bool add;
+                if (!scan) { const float f = wl ? wtop : 3.402823466e+38f; add = d < f || always_add; }
+                else { const double f = wl ? (double)wtop : 1.7976931348623157e+308; add = !(!always_add && (double)d >= f); }
+                if (!add) continue;
+                if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
+                c_push(it); PHeap<false>::push(WA, wl, it, lane); rlen++;
+                if (tm) cx.tph[8]++;
+                if (clen > cx.cmax) cx.cmax = clen;
+                if (rlen > ef) { (void)PHeap<false>::pop(WA, wl, lane); rlen--; }
             }
             __syncthreads();
-            if (tm) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); cx.tph[3] += t1 - t0; t0 = t1; }
+            F_TICK(6);
             cx.status = __shfl(cx.status, 0, 64);
             if (cx.status != FS_OK) break;
         }
     }
+    if (lane == 0) cx.CTL[1] = wl;
     __syncthreads();
 }
 
@@ -342,7 +450,7 @@ k_fused(const FusedParams p)
     cx.lane = threadIdx.x;
     cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
     cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
-    for (int i = 0; i < 5; i++) cx.tph[i] = 0;
+    for (int i = 0; i < 13; i++) cx.tph[i] = 0;
     const uint32_t lane = cx.lane;
 
     for (;;) {
@@ -438,7 +546,7 @@ k_fused(const FusedParams p)
         __syncthreads();
     }
     if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax);
-                     if (p.fdbg & 4u) { for (int i = 0; i < 4; i++) atomicAdd(&p.n_dist[3 + i], cx.tph[i]); } }
+                     if (p.fdbg & 4u) { for (int i = 0; i < 13; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
 }
 
 // ---- device graph mirror maintenance ------------------------------------------------------------------------
@@ -1044,7 +1152,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t out_n = mode == 0 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;
     const size_t cnt_n = mode == 0 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
     // device task/in/out buffers (one allocation, reused)
-    const size_t need = al16((size_t)ntasks * 4) * 3 + al16(out_n * 4) * 2 + al16(cnt_n * 4) + 64;
+    const size_t need = al16((size_t)ntasks * 4) * 3 + al16(out_n * 4) * 2 + al16(cnt_n * 4) + 256;
     if (need > mr.cap_io) {
         if (mr.d_io) (void)hipFree(mr.d_io);
         if (mr.h_io) (void)hipHostFree(mr.h_io);
@@ -1055,7 +1163,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         mr.cap_io = n;
     }
     size_t o = 0;
-    const size_t o_ctr = o; o += 64;
+    const size_t o_ctr = o; o += 256;
     const size_t o_q = o; o += al16((size_t)ntasks * 4);
     const size_t o_lv = o; o += al16((size_t)ntasks * 4);
     const size_t in_bytes = o;
@@ -1063,7 +1171,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t o_cnt = o; o += al16(cnt_n * 4);
     const size_t o_ids = o; o += al16(out_n * 4);
     const size_t o_d = o; o += al16(out_n * 4);
-    memset(mr.h_io + o_ctr, 0, 64);
+    memset(mr.h_io + o_ctr, 0, 256);
     memcpy(mr.h_io + o_q, q_sel, (size_t)ntasks * 4);
     if (t_level) memcpy(mr.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(mr.h_io + o_lv, 0, (size_t)ntasks * 4);
     HX_HIP(this, hipMemcpyAsync(mr.d_io, mr.h_io, in_bytes, hipMemcpyHostToDevice, stream));
@@ -1089,15 +1197,17 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
 #undef F16C
     HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
-    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, o - o_st, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
     memcpy(status, mr.h_io + o_st, (size_t)ntasks * 4);
     memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
     memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
     memcpy(out_d, mr.h_io + o_d, out_n * 4);
-    unsigned long long nd[7]; memcpy(nd, mr.h_io + o_ctr + 8, 56);
-    if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4)) fprintf(stderr, "[hx] k_fused mode %d phase clocks (sum over waves, 100 MHz ticks): pop %llu list+visited %llu dist %llu replay %llu; tasks %u\n", mode, nd[3], nd[4], nd[5], nd[6], ntasks);
+    unsigned long long nd[16]; memcpy(nd, mr.h_io + o_ctr + 8, 128);
+    if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))
+        fprintf(stderr, "[hx] k_fused mode %d tasks %u: 100 MHz ticks summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu\n",
+                mode, ntasks, nd[3], nd[4], nd[5], nd[6], nd[7], nd[8], nd[9], nd[10], nd[11], nd[12], nd[13], nd[14], nd[15]);
     if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }
     if (nd[2] > fused_cmax) fused_cmax = nd[2];
     if (timing) {
