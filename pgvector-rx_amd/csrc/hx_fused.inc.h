@@ -328,9 +328,11 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         if (cx.status != FS_OK) break;
         // pop the nearest candidate, decide whether to stop
         const bool tm = (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+        // The candidate about to be popped is the heap's root: read it, decide, and put its neighbour list's loads in
+        // flight BEFORE the pop's heap maintenance, which then hides that memory hop.
         uint32_t go = 0, cid = 0;
         if (clen > 0) {
-            const uint2 c = c_pop();
+            const uint2 c = PHeap<true>::ld(CA, 0u);
             const float cd = fh_d(c);
             bool stop;
             if (!scan) { const float f = wl ? __builtin_bit_cast(float, (unsigned int)WA[0].x) : 3.402823466e+38f; stop = cd > f; }                     // mod.rs:188-193
@@ -338,16 +340,19 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             if (!stop) { go = 1; cid = c.y; }
         }
         go = __builtin_amdgcn_readfirstlane(go); cid = __builtin_amdgcn_readfirstlane(cid);
+        const uint32_t *nb = p.l0_ids; uint32_t n = 0, lmax = 0, e_first = 0; int32_t clevel = 0x7fffffff;
+        if (go) {
+            if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; lmax = 2u * p.m; }
+            else { nb = p.up_ids + (size_t)(p.up_block[cid] + (uint32_t)(layer - 1)) * p.m; lmax = p.m; clevel = p.level[cid]; }
+            e_first = lane < lmax ? nb[lane] : 0u;                                   // issued together with the count: one memory hop
+            if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
+        }
+        if (clen > 0) (void)c_pop();                                                 // mod.rs:187 (the popped element is the root read above)
         F_TICK(0);
         if (!go) break;
         if (tm) cx.tph[7]++;
         // a linked element at layer 0 always has level >= 0, so the check of mod.rs:198-200 needs no load there
-        if (layer > 0 && p.level[cid] < layer) continue;
-        const uint32_t *nb; uint32_t n, lmax;
-        if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; lmax = 2u * p.m; }
-        else { nb = p.up_ids + (size_t)(p.up_block[cid] + (uint32_t)(layer - 1)) * p.m; lmax = p.m; }
-        const uint32_t e_first = lane < lmax ? nb[lane] : 0u;                        // issued together with the count: one memory hop
-        if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
+        if (layer > 0 && clevel < layer) continue;
         F_TICK(1);
         for (uint32_t n0 = 0; n0 < n; n0 += 64) {                                    // lists longer than a wave (m > 32) go in order
             const uint32_t idx = n0 + lane;
