@@ -34,13 +34,14 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include <float.h>
 
 #define ORC_API __attribute__((visibility("default")))
 
 enum { ORC_F32 = 0, ORC_F16 = 1, ORC_BIT = 2 };
 enum { ORC_L2SQ = 0, ORC_NEG_IP = 1, ORC_L1 = 2, ORC_HAMMING = 3, ORC_JACCARD = 4 };
-enum { ORC_ORDER_SEQ = 0, ORC_ORDER_W64 = 1 };
+enum { ORC_ORDER_SEQ = 0, ORC_ORDER_W64 = 1, ORC_ORDER_VEC = 2 };
 enum { ORC_ITER_OFF = 0, ORC_ITER_RELAXED = 1, ORC_ITER_STRICT = 2 };
 
 #define HNSW_HEAPTIDS 10 /* src/hnsw_constants.rs:85 */
@@ -146,8 +147,36 @@ static float acc_w64(int kind, int dtype, int dim, const void *a, const void *b)
     return p[0];
 }
 
+/* ORC_ORDER_VEC: a reassociated, compiler-vectorised CPU variant (16 partial sums, AVX-512 / AVX2 picked at load time).
+ * It is NOT the reference's arithmetic (the reference is the scalar loop above); it exists only so that bench.py can
+ * also quote the GPU against a CPU baseline that is not handicapped by the reference's dependent add chain
+ * ("vectorised CPU variant").  f32 rows only; halfvec falls back to the scalar order. */
+#define VEC_LOOP(EXPR)                                                                         \
+    float acc[16] = {0};                                                                       \
+    int i = 0;                                                                                 \
+    for (; i + 16 <= dim; i += 16)                                                             \
+        for (int j = 0; j < 16; j++) { const float x = a[i + j], y = b[i + j]; acc[j] += (EXPR); } \
+    float tail = 0.0f;                                                                         \
+    for (; i < dim; i++) { const float x = a[i], y = b[i]; tail += (EXPR); }                   \
+    for (int w = 8; w >= 1; w >>= 1) for (int j = 0; j < w; j++) acc[j] += acc[j + w];         \
+    return acc[0] + tail;
+__attribute__((optimize("O3"), target_clones("avx512f", "avx2", "default")))
+static float vec_l2(const float *a, const float *b, int dim) { VEC_LOOP((x - y) * (x - y)) }
+__attribute__((optimize("O3"), target_clones("avx512f", "avx2", "default")))
+static float vec_ip(const float *a, const float *b, int dim) { VEC_LOOP(x * y) }
+__attribute__((optimize("O3"), target_clones("avx512f", "avx2", "default")))
+static float vec_l1(const float *a, const float *b, int dim) { VEC_LOOP(fabsf(x - y)) }
+static float acc_vec(int kind, int dtype, int dim, const void *a, const void *b)
+{
+    if (dtype != ORC_F32) return acc_seq(kind, dtype, dim, a, b);
+    if (kind == T_L2) return vec_l2((const float *)a, (const float *)b, dim);
+    if (kind == T_IP) return vec_ip((const float *)a, (const float *)b, dim);
+    return vec_l1((const float *)a, (const float *)b, dim);
+}
+
 static inline float acc_f(int kind, int dtype, int dim, const void *a, const void *b, int order)
 {
+    if (order == ORC_ORDER_VEC) return acc_vec(kind, dtype, dim, a, b);
     return order == ORC_ORDER_SEQ ? acc_seq(kind, dtype, dim, a, b) : acc_w64(kind, dtype, dim, a, b);
 }
 
@@ -688,6 +717,7 @@ ORC_API void orc_update_neighbor_connections_raw(orc_index *x, int new_idx) { up
 /* scan: in-memory mirror of src/index/scan.rs (rows addressed by element
  * index instead of (blkno, offno); no deleted tuples, no stale versions) */
 /* ------------------------------------------------------------------ */
+static __thread int tl_nocount = 0;   /* set by orc_search_many's workers: the shared counters are not atomic */
 typedef struct orc_scan {
     orc_index *x; void *q; int q_null;
     int ef_search, iterative; int64_t max_scan_tuples;
@@ -700,7 +730,7 @@ typedef struct orc_scan {
 static inline double dist_scan(orc_scan *s, int e)
 {   /* load_element scan.rs:186-192: NULL query => 0.0 */
     if (s->q_null) return 0.0;
-    s->x->cnt[4]++;
+    if (!tl_nocount) s->x->cnt[4]++;
     return orc_distance(s->x->dtype, s->x->metric, s->x->dim, s->q, rowp(s->x, e), s->x->order);
 }
 
@@ -848,6 +878,33 @@ ORC_API int orc_search_topk(orc_index *x, const void *query, int ef_search, int 
     while (n < k && orc_scan_next(s, &t, &d, &e)) { ids[n] = e; dist[n] = d; n++; }
     orc_scan_end(s);
     return n;
+}
+
+/* the same scan for nq queries on n_threads host threads, one query per thread at a time (one backend per connection in
+ * the reference's process model); read-only on the index.  ids_out[nq][k], cnt_out[nq]. */
+typedef struct { orc_index *x; const uint8_t *q; size_t qb; int nq, ef, k, tid, nthr; int *ids; int *cnt; } many_arg;
+static void *many_worker(void *vp)
+{
+    many_arg *a = (many_arg *)vp;
+    tl_nocount = 1;
+    double *d = malloc((size_t)a->k * sizeof(double));
+    for (int q = a->tid; q < a->nq; q += a->nthr)
+        a->cnt[q] = orc_search_topk(a->x, a->q + (size_t)q * a->qb, a->ef, a->k, a->ids + (size_t)q * a->k, d);
+    free(d);
+    return NULL;
+}
+ORC_API void orc_search_many(orc_index *x, const void *queries, int nq, int ef_search, int k, int n_threads, int *ids_out, int *cnt_out)
+{
+    if (n_threads < 1) n_threads = 1;
+    (void)popcnt_table();
+    pthread_t *th = malloc((size_t)n_threads * sizeof(pthread_t));
+    many_arg *args = malloc((size_t)n_threads * sizeof(many_arg));
+    for (int t = 0; t < n_threads; t++) {
+        args[t] = (many_arg){ x, (const uint8_t *)queries, x->row_bytes, nq, ef_search, k, t, n_threads, ids_out, cnt_out };
+        pthread_create(&th[t], NULL, many_worker, &args[t]);
+    }
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    free(th); free(args);
 }
 
 /* exact brute force top-k (ground truth for recall; distances in the index's order) */

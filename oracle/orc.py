@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "_build", "liborc.so")
 
 F32, F16, BIT = 0, 1, 2
 L2SQ, NEG_IP, L1, HAMMING, JACCARD = 0, 1, 2, 3, 4
-SEQ, W64 = 0, 1
+SEQ, W64, VEC = 0, 1, 2     # VEC: reassociated + compiler-vectorised CPU variant (bench baseline only, not the reference's arithmetic)
 ITER_OFF, ITER_RELAXED, ITER_STRICT = 0, 1, 2
 
 _lib = None
@@ -71,6 +71,7 @@ def lib():
             "orc_scan_end": (None, [vp]),
             "orc_scan_next": (i32, [vp, vp, vp, vp]),
             "orc_search_topk": (i32, [vp, vp, i32, i32, vp, vp]),
+            "orc_search_many": (None, [vp, vp, i32, i32, i32, i32, vp, vp]),
             "orc_bruteforce_topk": (i32, [vp, vp, i32, vp, vp]),
             "orc_distances_many": (None, [i32, i32, i32, vp, vp, vp, i32, i32, vp]),
             "orc_pairwise": (None, [i32, i32, i32, vp, vp, i32, i32, vp]),
@@ -275,6 +276,15 @@ class Index:
         d = np.empty(k, np.float64)
         n = lib().orc_search_topk(self.h, _p(q), ef_search, k, _p(ids), _p(d))
         return ids[:n].copy(), d[:n].copy()
+
+    def search_many(self, queries, ef_search, k, n_threads=1):
+        """The same scan for many queries on n_threads host threads (one query per thread at a time)."""
+        q = as_rows(self.dtype, queries)
+        nq = q.shape[0] if q.ndim > 1 else 1
+        ids = np.full((nq, k), -1, np.int32)
+        cnt = np.zeros(nq, np.int32)
+        lib().orc_search_many(self.h, _p(q), nq, ef_search, k, int(n_threads), _p(ids), _p(cnt))
+        return ids, cnt
 
     def bruteforce_topk(self, query, k):
         q = as_rows(self.dtype, query)

@@ -287,3 +287,28 @@ def test_recall_gates(gate):
             correct += sum(1 for t in got if t in okset) if tname == "bit" else len(okset & set(got))
             total += k
         assert correct / total >= min_recall, (metric, correct / total)
+
+
+def test_search_many_threads_equal_single_and_vec_order_within_tolerance():
+    """orc_search_many (bench.py's all-cores CPU leg) returns what orc_search_topk returns per query, on any thread count;
+    ORC_ORDER_VEC (the reassociated, vectorised CPU baseline) stays within 1e-5 relative of the reference's scalar order."""
+    rng = np.random.default_rng(3)
+    n, dim = 600, 48
+    rows = rng.random((n, dim), dtype=np.float32)
+    qs = rng.random((17, dim), dtype=np.float32)
+    levels = orc.levels_from_seed(n, 8, 5)
+    x = orc.Index(orc.F32, orc.L2SQ, dim, m=8, ef_construction=32, order=orc.SEQ)
+    x.build(rows, levels, batch=1)
+    ids1, cnt1 = x.search_many(qs, 24, 5, n_threads=1)
+    ids4, cnt4 = x.search_many(qs, 24, 5, n_threads=4)
+    assert np.array_equal(ids1, ids4) and np.array_equal(cnt1, cnt4)
+    for q in range(len(qs)):
+        ids, _ = x.search_topk(qs[q], 24, 5)
+        assert ids.tolist() == ids1[q, :cnt1[q]].tolist()
+    for metric in (orc.L2SQ, orc.NEG_IP, orc.L1):
+        for d in (1, 15, 16, 17, 48, 131):
+            a, b = rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)
+            s = orc.distance(orc.F32, metric, d, a, b, order=orc.SEQ)
+            v = orc.distance(orc.F32, metric, d, a, b, order=orc.VEC)
+            scale = float(np.abs(a.astype(np.float64) * b).sum()) if metric == orc.NEG_IP else abs(s)
+            assert abs(s - v) <= 1e-5 * max(scale, 1e-30)
