@@ -41,6 +41,7 @@ struct FusedParams {
     uint32_t *next_task;
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
+    float *dsc;                                   // 64 floats of LDS scratch for the short-row distance path (set inside the kernels)
     uint32_t fdbg;                                // experiments (HX_F_DBG): 1 no pre-filter, 4 phase timers into n_dist[3..7]
 };
 
@@ -221,12 +222,52 @@ __device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src,
     __syncthreads();
 }
 
+// Short rows (payload <= 512 B: bit(1024), vector(128), the reference's 3-d tests): a 64-lane wave per row would leave
+// most lanes idle and cost one memory hop per FUSED_RB rows.  Here LPR = 8/16/32 lanes share a row (as K1 does), 64/LPR rows
+// are read by ONE load instruction, and up to eight such instructions are in flight, so a whole neighbour list is one hop.
+// The bits are the canonical ones: the lanes a short row does not reach contribute +0.0 partials in the 64-lane order.
+template <class OP, int LPR>
+__device__ __forceinline__ float f_dist_small(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
+{
+    constexpr int R = 64 / LPR, PF = 8;
+    const uint32_t g = lane / LPR, loff = (lane % LPR) * 16u;
+    const bool in = loff < p.pitch;
+    u4 q = {0u, 0u, 0u, 0u};
+    if (in) q = *(const u4 *)(qv + loff);
+    for (uint32_t j0 = 0; j0 < n; j0 += R * PF) {
+        u4 rv[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const uint32_t j = j0 + (uint32_t)k * R + g;
+            u4 v = {0u, 0u, 0u, 0u};
+            if (in && j < n) v = *(const u4 *)(p.rows + (size_t)ids[j] * p.pitch + loff);
+            rv[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const uint32_t j = j0 + (uint32_t)k * R + g;
+            if (j0 + (uint32_t)k * R < n) {                       // wave-uniform: this pass holds at least one row
+                typename OP::acc_t acc; OP::init(acc); OP::add(acc, q, rv[k]);
+                const float d = OP::template finish<LPR>(acc);
+                if (loff == 0u && j < n) p.dsc[j] = d;
+            }
+        }
+    }
+    F_WSYNC();
+    const float mine = lane < n ? p.dsc[lane] : 0.0f;
+    F_WSYNC();
+    return mine;
+}
+// rows evaluated per early-exit step of check_element_closer: eight on the short-row path, else FUSED_RB
+template <int LPR> __device__ __forceinline__ constexpr uint32_t f_step_rows() { return LPR < 64 ? 8u : (uint32_t)FUSED_RB; }
+
 // distances from the vector parked at `qv` (LDS) to rows ids[0..n) (LDS); lane j (< 64) returns d(q, ids[j]); n <= 64.
 // FUSED_RB rows x FUSED_CG 1-KiB chunks are requested at once (one HBM latency per row batch at d <= 768 f32), then
 // consumed chunk by chunk in ascending order -- the canonical per-lane order.
-template <class OP>
+template <class OP, int LPR>
 __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
+    if constexpr (LPR < 64) return f_dist_small<OP, LPR>(p, qv, ids, n, lane);
     float mine = 0.0f;
     unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
 #define FD_TICK(k) do { if (tk) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[k] += (uint32_t)(t_ - tq); tq = t_; } } while (0)
@@ -276,13 +317,14 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
 // check_element_closer (graph/mod.rs:315-339): is any d(q, ids[j]) <= thr?  Rows are evaluated FUSED_RB at a time in list
 // order and the scan stops at the first batch that contains a hit, like the reference's early `return false`
 // (the answer is the same; fewer rows are streamed for rejected candidates).  *n_eval += rows evaluated.
-template <class OP>
+template <class OP, int LPR>
 __device__ __forceinline__ bool f_any_le(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
                                          unsigned long long &n_eval)
 {
-    for (uint32_t j0 = 0; j0 < n; j0 += FUSED_RB) {
-        const uint32_t nb = n - j0 < FUSED_RB ? n - j0 : FUSED_RB;
-        const float d = f_dist_batch<OP>(p, qv, ids + j0, nb, lane);
+    constexpr uint32_t B = f_step_rows<LPR>();
+    for (uint32_t j0 = 0; j0 < n; j0 += B) {
+        const uint32_t nb = n - j0 < B ? n - j0 : B;
+        const float d = f_dist_batch<OP, LPR>(p, qv, ids + j0, nb, lane);
         n_eval += nb;
         if (__ballot(lane < nb && d <= thr) != 0ull) return true;
     }
@@ -292,7 +334,7 @@ __device__ __forceinline__ bool f_any_le(const FusedParams &p, const uint8_t *qv
 // Algorithm 2 with entry points EP[0..n_ep); leaves the result set in the W heap (cx.CTL[1] = |W|).
 // scan == false: search_layer (graph/mod.rs:161-255); scan == true: search_layer_disk without `discarded` (scan.rs:302-448).
 #define F_TICK(k) do { if (tm) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); cx.tph[k] += (uint32_t)(t1_ - t0); t0 = t1_; } } while (0)
-template <class OP>
+template <class OP, int LPR>
 __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan)
 {
     const uint32_t lane = cx.lane;
@@ -374,7 +416,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
             __syncthreads();
             F_TICK(3);
-            const float mine = f_dist_batch<OP>(p, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
+            const float mine = f_dist_batch<OP, LPR>(p, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
             F_TICK(4);
             vis_settle(cx.vis, bmask, e, vslot, vold);                               // the CAS results came back with the rows
             if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
@@ -431,10 +473,11 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
     __syncthreads();
 }
 
-template <class OP, int MODE>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors)
+template <class OP, int MODE, int LPR>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors); LPR: lanes per row (64, or 8/32 for short rows)
 __global__ void __launch_bounds__(64, FUSED_MINW)
-k_fused(const FusedParams p)
+k_fused(const FusedParams p_in)
 {
+    FusedParams p = p_in;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     FusedCtx cx;
     const uint32_t lm0 = 2u * p.m;
@@ -447,7 +490,8 @@ k_fused(const FusedParams p)
     cx.RL = cx.RES + 64;
     cx.IDS = (uint32_t *)(cx.RL + lm0);
     cx.CTL = cx.IDS + 64;
-    cx.QV = (uint8_t *)(cx.CTL + 16);                     // query parked in LDS (nch KiB)
+    p.dsc = (float *)(cx.CTL + 16);
+    cx.QV = (uint8_t *)(p.dsc + 64);                      // query parked in LDS (nch KiB)
     cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
     cx.CH.lds = (lds_uint2 *)cx.C; cx.CH.glob = p.spill + (size_t)blockIdx.x * p.spill_stride; cx.CH.L = p.clds;
@@ -474,7 +518,7 @@ k_fused(const FusedParams p)
         // d(q, entry point): mod.rs:371-377 / scan.rs:475
         if (lane == 0) cx.IDS[0] = p.entry;
         __syncthreads();
-        const float d0 = f_dist_batch<OP>(p, cx.QV, cx.IDS, 1, lane);
+        const float d0 = f_dist_batch<OP, LPR>(p, cx.QV, cx.IDS, 1, lane);
         cx.nd0 += 1;
         if (lane == 0) cx.EP[0] = fh_pack(d0, p.entry);
         __syncthreads();
@@ -483,7 +527,7 @@ k_fused(const FusedParams p)
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
         const int stop_above = MODE == 1 ? new_level : 0;
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
-            f_search_layer<OP>(p, cx, n_ep, 1u, lc, MODE == 0);
+            f_search_layer<OP, LPR>(p, cx, n_ep, 1u, lc, MODE == 0);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
                 f_sort_results(cx, wl, MODE == 0);
@@ -495,7 +539,7 @@ k_fused(const FusedParams p)
         if (MODE == 0) {
             uint32_t cnt = 0;
             if (cx.status == FS_OK && n_ep > 0) {
-                f_search_layer<OP>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
+                f_search_layer<OP, LPR>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, true);                                        // nearest LAST
                 cnt = wl < p.k ? wl : p.k;
@@ -511,7 +555,7 @@ k_fused(const FusedParams p)
             for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
             for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
                 const uint32_t lm = lc == 0 ? lm0 : p.m;
-                f_search_layer<OP>(p, cx, n_ep, p.ef, lc, false);                // mod.rs:407-416
+                f_search_layer<OP, LPR>(p, cx, n_ep, p.ef, lc, false);                // mod.rs:407-416
                 if (cx.status != FS_OK) break;
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
@@ -529,7 +573,7 @@ k_fused(const FusedParams p)
                         if (r > 0) {
                             if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
                             f_park(p, p.rows + (size_t)e.y * p.pitch, lane, cx.EV);
-                            closer = !f_any_le<OP>(p, cx.EV, cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
+                            closer = !f_any_le<OP, LPR>(p, cx.EV, cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
                             __syncthreads();
                         }
                         if (lane == 0) { if (closer) cx.RL[r] = e; else cx.DL[nd] = e; }
@@ -833,7 +877,7 @@ k_links(const LinksParams p)
 #define LC_TRI (LC_SLOTS * (LC_SLOTS - 1) / 2)     /* 496 */
 __device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > j ? i * (i - 1) / 2 + j : j * (j - 1) / 2 + i; }
 
-template <class OP>
+template <class OP, int LPR>
 __global__ void __launch_bounds__(64, 4)
 k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
 {
@@ -847,11 +891,12 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     uint32_t *pos = (uint32_t *)(nd + 40);         // sorted candidate k -> slot (LC_SLOTS = the new row)
     float *sd = (float *)(pos + 40);
     uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *ORD = dis + 40, *IDS = ORD + 40;   // IDS[64]
-    uint8_t *QV = (uint8_t *)(IDS + 64);
+    float *DSC = (float *)(IDS + 64);
+    uint8_t *QV = (uint8_t *)(DSC + 64);
     const uint32_t lane = threadIdx.x;
     const uint32_t g = blockIdx.x;
     if (g >= p.n_groups) return;
-    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u;
+    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u; fp.dsc = DSC;
     const uint32_t target = p.target[g], layer = p.layer[g];
     const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
     uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
@@ -878,7 +923,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
         for (uint32_t sl = v < 1 ? 1 : v; sl < cnt; sl++) {
             if (lane < sl) IDS[lane] = lid[lane];
             f_park(fp, p.rows + (size_t)lid[sl] * p.pitch, lane, QV);
-            const float d = f_dist_batch<OP>(fp, QV, IDS, sl, lane);
+            const float d = f_dist_batch<OP, LPR>(fp, QV, IDS, sl, lane);
             if (lane < sl) M[sl * (sl - 1) / 2 + lane] = d;
             ndist += sl;
             __syncthreads();
@@ -906,7 +951,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
                 ordered = true;
             }
             if (n_done < cnt) {
-                const float d = f_dist_batch<OP>(fp, QV, IDS + n_done, cnt - n_done, lane);
+                const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + n_done, cnt - n_done, lane);
                 if (lane < cnt - n_done) nd[ORD[n_done + lane]] = d;
                 ndist += cnt - n_done; n_done = cnt;
             }
@@ -928,9 +973,10 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
                 f_park(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
                 ordered = true;
                 bool hit = false;
-                for (uint32_t j0 = 0; j0 < na && !hit; j0 += FUSED_RB) {
-                    const uint32_t nb = na - j0 < FUSED_RB ? na - j0 : FUSED_RB;
-                    const float d = f_dist_batch<OP>(fp, QV, IDS + j0, nb, lane);
+                constexpr uint32_t B = f_step_rows<LPR>();
+                for (uint32_t j0 = 0; j0 < na && !hit; j0 += B) {
+                    const uint32_t nb = na - j0 < B ? na - j0 : B;
+                    const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + j0, nb, lane);
                     if (lane < nb) nd[ORD[j0 + lane]] = d;
                     ndist += nb; n_done = j0 + nb;
                     hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
@@ -983,13 +1029,20 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     if (lane == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
 }
 
-template <class OP>
-static hipError_t launch_links_cached(hx_engine *e, const LinksParams &p)
+template <class OP, int LPR>
+static hipError_t launch_links_cached_lpr(hx_engine *e, const LinksParams &p)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
-    const size_t lds = (528 * 2 + 40 * 11 + 64) * 4 + nch * 1024;
-    hipLaunchKernelGGL((k_links_cached<OP>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    const size_t lds = (528 * 2 + 40 * 11 + 64 + 64) * 4 + nch * 1024;
+    hipLaunchKernelGGL((k_links_cached<OP, LPR>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
     return hipGetLastError();
+}
+template <class OP>
+static hipError_t launch_links_cached(hx_engine *e, const LinksParams &p)
+{   // lanes per row by payload: <= 128 B (bit(1024), tiny test vectors) 8, <= 512 B (vector(128)) 32, else the whole wave
+    if (e->pitch <= 128) return launch_links_cached_lpr<OP, 8>(e, p);
+    if (e->pitch <= 512) return launch_links_cached_lpr<OP, 32>(e, p);
+    return launch_links_cached_lpr<OP, 64>(e, p);
 }
 
 template <class OP>
@@ -1097,28 +1150,35 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     return HX_OK;
 }
 
-template <class OP, int MODE>
+template <class OP, int MODE, int LPR>
 static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds)
 {
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        hipError_t s = hipFuncSetAttribute((const void *)k_fused<OP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        hipError_t s = hipFuncSetAttribute((const void *)k_fused<OP, MODE, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         if (s != hipSuccess) return s;
         attr_set = true;
     }
     if (getenv("HX_DEBUG")) {
         static thread_local bool once = false;
-        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_fused<OP, MODE>, 64, lds);
-            fprintf(stderr, "[hx] k_fused<mode %d>: dynamic LDS %zu B, grid %u, occupancy API says %d blocks/CU\n", MODE, lds, grid, nb); }
+        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_fused<OP, MODE, LPR>, 64, lds);
+            fprintf(stderr, "[hx] k_fused<mode %d, %d lanes/row>: dynamic LDS %zu B, grid %u, occupancy API says %d blocks/CU\n", MODE, LPR, lds, grid, nb); }
     }
-    hipLaunchKernelGGL((k_fused<OP, MODE>), dim3(grid), dim3(64), lds, e->stream, p);
+    hipLaunchKernelGGL((k_fused<OP, MODE, LPR>), dim3(grid), dim3(64), lds, e->stream, p);
     return hipGetLastError();
 }
 
+template <class OP, int LPR>
+static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
+{
+    return mode == 0 ? launch_fused<OP, 0, LPR>(e, p, grid, lds) : launch_fused<OP, 1, LPR>(e, p, grid, lds);
+}
 template <class OP>
 static hipError_t launch_fused_mode(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
-{
-    return mode == 0 ? launch_fused<OP, 0>(e, p, grid, lds) : launch_fused<OP, 1>(e, p, grid, lds);
+{   // lanes per row by payload, as in launch_links_cached
+    if (e->pitch <= 128) return launch_fused_lpr<OP, 8>(e, p, grid, lds, mode);
+    if (e->pitch <= 512) return launch_fused_lpr<OP, 32>(e, p, grid, lds, mode);
+    return launch_fused_lpr<OP, 64>(e, p, grid, lds, mode);
 }
 
 // mode 0: ntasks queries -> out_ids/out_d [ntasks][k], out_cnt[ntasks]; mode 1: ntasks inserts -> out_ids/out_d
@@ -1139,8 +1199,9 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t nch_ = (pitch + 1023) / 1024;
     const uint32_t ccap = FUSED_CCAP;
     uint32_t clds = mode == 1 ? 1024u : 512u;
+    { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
     clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16) * 4 + nch_ * 1024; };
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024; };
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
