@@ -225,6 +225,26 @@ int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int
                               uint32_t limit, const uint8_t *filter_pass, uint64_t n_filter,
                               int64_t *tids_out, float *dist_out, uint32_t *counts_out);
 
+/* ---- graph -> PostgreSQL index pages -----------------------------------------
+ * Serialises the built graph as the byte image of the HNSW relation fork, exactly as ambuild flushes it:
+ * create_meta_page + create_graph_pages + write_neighbor_tuples + update_meta_page (src/index/build.rs:545-821)
+ * with the page structures of src/types/hnsw.rs:20-169 (meta page: magic 0xA953A953, version 1; element tuple:
+ * 72-byte header {type 1, level, deleted, version, 10 heap TIDs, neighbour TID} + the value's varlena; neighbour
+ * tuple: {type 2, version, count} + (level+2)*m index TIDs, layers top -> 0, invalid-TID padding; element and
+ * neighbour tuple co-located when both fit; pages chained through the special area's nextblkno, page_id 0xFF90).
+ * Page 0 is the meta page, data pages follow; every page is HX_PAGE_SIZE bytes (BLCKSZ 8192, layout version 4).
+ * The value varlena is rebuilt from the engine's payload: {vl_len_ = size << 2, dim:i16, unused:i16} for
+ * vector / halfvec (vector.rs:43-48, halfvec.rs:41-46), {vl_len_, bit_len:i32} for bit (bitvec.rs:28-37).
+ * Heap TIDs: the int64 tids given to hx_index_insert are read as (block << 16) | offset.
+ * Tombstoned duplicates (merged into another element's heap TIDs) get no tuples, as in build.rs:482-512.
+ *   pages_out == NULL: only computes *n_pages_out (and the element locations, if asked);
+ *   else writes min(cap_pages, needed) pages and fails with HX_E_ARG when cap_pages is too small.
+ * elem_blkno_out / elem_offno_out (nullable, one per element): where each element tuple went (0xFFFFFFFF / 0 for
+ * tombstones) -- the host's disk_locs (build.rs:283-285). */
+#define HX_PAGE_SIZE 8192
+int hx_index_serialize_pages(const hx_index *ix, uint8_t *pages_out, uint64_t cap_pages, uint64_t *n_pages_out,
+                             uint32_t *elem_blkno_out, uint16_t *elem_offno_out);
+
 #ifdef __cplusplus
 }
 #endif

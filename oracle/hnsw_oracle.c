@@ -907,6 +907,165 @@ ORC_API void orc_search_many(orc_index *x, const void *queries, int nq, int ef_s
     free(th); free(args);
 }
 
+/* ------------------------------------------------------------------ */
+/* the index as PostgreSQL pages, restated from       */
+/* build.rs:545-821 step by step (create_meta_page, create_graph_pages  */
+/* with placeholder neighbour tuples, write_neighbor_tuples,            */
+/* update_meta_page) on top of the four bufpage.c primitives the        */
+/* reference calls.  Pages live in one caller buffer; block b is at     */
+/* b * 8192.                                                            */
+/* ------------------------------------------------------------------ */
+#define PG_BLCKSZ 8192u
+typedef struct { uint32_t pd_lsn_hi, pd_lsn_lo; uint16_t pd_checksum, pd_flags, pd_lower, pd_upper, pd_special, pd_pagesize_version; uint32_t pd_prune_xid; } pg_page_header;   /* 24 bytes */
+typedef struct { uint16_t bi_hi, bi_lo, ip_posid; } pg_tid;                                  /* ItemPointerData */
+typedef struct { uint32_t nextblkno; uint16_t unused, page_id; } hnsw_opaque;                /* types/hnsw.rs:17-27 */
+typedef struct { uint32_t magic_number, version, dimensions; uint16_t m, ef_construction; uint32_t entry_blkno; uint16_t entry_offno; int16_t entry_level; uint32_t insert_page; } hnsw_meta;   /* types/hnsw.rs:52-72 */
+typedef struct { uint8_t type_, level, deleted, version; pg_tid heaptids[HNSW_HEAPTIDS]; pg_tid neighbortid; uint16_t unused; } hnsw_etup;   /* types/hnsw.rs:110-126 */
+typedef struct { uint8_t type_, version; uint16_t count; } hnsw_ntup;                        /* types/hnsw.rs:149-157 */
+static size_t pg_maxalign(size_t x) { return (x + 7u) & ~(size_t)7u; }                       /* types/hnsw.rs:316-319 */
+static void pg_tid_set(pg_tid *t, uint32_t blk, uint16_t off) { t->bi_hi = (uint16_t)(blk >> 16); t->bi_lo = (uint16_t)(blk & 0xffff); t->ip_posid = off; }
+static void pg_tid_invalid(pg_tid *t) { pg_tid_set(t, 0xFFFFFFFFu, 0); }
+static void pg_page_init(uint8_t *page, size_t special)
+{   /* PageInit */
+    memset(page, 0, PG_BLCKSZ);
+    pg_page_header *h = (pg_page_header *)page;
+    h->pd_lower = (uint16_t)sizeof(pg_page_header);
+    h->pd_upper = (uint16_t)(PG_BLCKSZ - pg_maxalign(special));
+    h->pd_special = h->pd_upper;
+    h->pd_pagesize_version = (uint16_t)(PG_BLCKSZ | 4u);
+}
+static size_t pg_page_free_space(const uint8_t *page)
+{   /* PageGetFreeSpace */
+    const pg_page_header *h = (const pg_page_header *)page;
+    int space = (int)h->pd_upper - (int)h->pd_lower;
+    return space < 4 ? 0 : (size_t)(space - 4);
+}
+static uint16_t pg_page_max_offset(const uint8_t *page)
+{   /* PageGetMaxOffsetNumber */
+    const pg_page_header *h = (const pg_page_header *)page;
+    return h->pd_lower <= sizeof(pg_page_header) ? 0 : (uint16_t)((h->pd_lower - sizeof(pg_page_header)) / 4);
+}
+static uint16_t pg_page_add_item(uint8_t *page, const void *item, size_t size)
+{   /* PageAddItemExtended(page, item, size, InvalidOffsetNumber, 0) */
+    pg_page_header *h = (pg_page_header *)page;
+    uint16_t off = (uint16_t)(pg_page_max_offset(page) + 1);
+    int lower = h->pd_lower + 4, upper = (int)h->pd_upper - (int)pg_maxalign(size);
+    if (lower > upper) return 0;
+    uint32_t lp = (uint32_t)upper | (1u << 15) | ((uint32_t)size << 17);    /* ItemIdSetNormal: lp_off:15, lp_flags:2 = LP_NORMAL, lp_len:15 */
+    memcpy(page + h->pd_lower, &lp, 4);
+    memcpy(page + upper, item, size);
+    h->pd_lower = (uint16_t)lower; h->pd_upper = (uint16_t)upper;
+    return off;
+}
+static int pg_page_overwrite(uint8_t *page, uint16_t off, const void *item, size_t size)
+{   /* PageIndexTupleOverwrite with an unchanged MAXALIGNed size */
+    uint32_t lp; memcpy(&lp, page + sizeof(pg_page_header) + (size_t)(off - 1) * 4, 4);
+    uint32_t lp_off = lp & 0x7fff, lp_len = lp >> 17;
+    if (pg_maxalign(lp_len) != pg_maxalign(size)) return 0;
+    memcpy(page + lp_off, item, size);
+    lp = lp_off | (1u << 15) | ((uint32_t)size << 17);
+    memcpy(page + sizeof(pg_page_header) + (size_t)(off - 1) * 4, &lp, 4);
+    return 1;
+}
+static void hnsw_init_page(uint8_t *page)
+{   /* build.rs:59-65 */
+    pg_page_init(page, sizeof(hnsw_opaque));
+    hnsw_opaque *o = (hnsw_opaque *)(page + ((pg_page_header *)page)->pd_special);
+    o->nextblkno = 0xFFFFFFFFu; o->page_id = 0xFF90;
+}
+typedef struct { uint32_t blkno; uint16_t offno; uint32_t neighbor_page; uint16_t neighbor_offno; } disk_loc;   /* build.rs:283-285 */
+
+/* Returns the number of pages (0 on error: tuple too large, cap too small, add failure).  blk_out/off_out per element (nullable). */
+ORC_API uint64_t orc_index_write_pages(const orc_index *x, uint8_t *pages, uint64_t cap_pages, uint32_t *blk_out, uint16_t *off_out)
+{
+    const size_t max_size = PG_BLCKSZ - pg_maxalign(sizeof(pg_page_header)) - pg_maxalign(sizeof(hnsw_opaque)) - 4;   /* types/hnsw.rs:325-331 */
+    const size_t value_size = 8 + x->row_bytes;                                  /* varlena header + payload */
+    if (cap_pages < 2) return 0;
+    /* create_meta_page */
+    uint8_t *mp = pages;
+    hnsw_init_page(mp);
+    hnsw_meta *meta = (hnsw_meta *)(mp + sizeof(pg_page_header));
+    meta->magic_number = 0xA953A953u; meta->version = 1; meta->dimensions = (uint32_t)x->dim;
+    meta->m = (uint16_t)x->m; meta->ef_construction = (uint16_t)x->efc;
+    meta->entry_blkno = 0xFFFFFFFFu; meta->entry_offno = 0; meta->entry_level = -1; meta->insert_page = 0xFFFFFFFFu;
+    ((pg_page_header *)mp)->pd_lower = (uint16_t)(sizeof(pg_page_header) + sizeof(hnsw_meta));
+    /* create_graph_pages */
+    uint32_t blk = 1;
+    uint8_t *page = pages + (size_t)blk * PG_BLCKSZ;
+    hnsw_init_page(page);
+    disk_loc *locs = calloc((size_t)x->n + 1, sizeof(disk_loc));
+    uint8_t *etup_buf = calloc(1, PG_BLCKSZ), *ntup_buf = calloc(1, PG_BLCKSZ);
+    uint64_t result = 0;
+    for (int idx = 0; idx < x->n; idx++) {
+        const elem_t *el = &x->el[idx];
+        locs[idx].blkno = 0xFFFFFFFFu;
+        if (el->merged) continue;                                                /* the reference pops a merged duplicate from `elements` (build.rs:507-509) */
+        size_t etup_size = pg_maxalign(sizeof(hnsw_etup) + value_size);
+        size_t ntup_size = pg_maxalign(sizeof(hnsw_ntup) + (size_t)(el->level + 2) * x->m * sizeof(pg_tid));
+        size_t combined = etup_size + ntup_size + 4;
+        if (etup_size > max_size) goto done;
+        memset(etup_buf, 0, etup_size);
+        hnsw_etup *et = (hnsw_etup *)etup_buf;
+        et->type_ = 1; et->level = (uint8_t)el->level; et->deleted = 0; et->version = 0;
+        for (int i = 0; i < HNSW_HEAPTIDS; i++) {
+            if (i < el->ntids) pg_tid_set(&et->heaptids[i], (uint32_t)((uint64_t)el->tids[i] >> 16), (uint16_t)(el->tids[i] & 0xffff));
+            else pg_tid_invalid(&et->heaptids[i]);
+        }
+        uint8_t *v = etup_buf + sizeof(hnsw_etup);
+        uint32_t vl = (uint32_t)value_size << 2; memcpy(v, &vl, 4);
+        if (x->dtype == ORC_BIT) { int32_t bl = x->dim; memcpy(v + 4, &bl, 4); } else { int16_t d16 = (int16_t)x->dim, z = 0; memcpy(v + 4, &d16, 2); memcpy(v + 6, &z, 2); }
+        memcpy(v + 8, rowp((orc_index *)x, idx), x->row_bytes);
+        size_t fs = pg_page_free_space(page);
+        if (fs < etup_size || (combined <= max_size && fs < combined)) {         /* hnsw_build_append_page */
+            if ((uint64_t)blk + 2 > cap_pages) goto done;
+            ((hnsw_opaque *)(page + ((pg_page_header *)page)->pd_special))->nextblkno = blk + 1;
+            blk++; page = pages + (size_t)blk * PG_BLCKSZ; hnsw_init_page(page);
+        }
+        uint32_t eblk = blk; uint16_t eoff = (uint16_t)(pg_page_max_offset(page) + 1);
+        uint32_t nblk; uint16_t noff;
+        if (combined <= max_size) { nblk = eblk; noff = (uint16_t)(eoff + 1); } else { nblk = eblk + 1; noff = 1; }
+        locs[idx] = (disk_loc){ eblk, eoff, nblk, noff };
+        pg_tid_set(&et->neighbortid, nblk, noff);
+        if (pg_page_add_item(page, etup_buf, etup_size) != eoff) goto done;
+        if (pg_page_free_space(page) < ntup_size) {
+            if ((uint64_t)blk + 2 > cap_pages) goto done;
+            ((hnsw_opaque *)(page + ((pg_page_header *)page)->pd_special))->nextblkno = blk + 1;
+            blk++; page = pages + (size_t)blk * PG_BLCKSZ; hnsw_init_page(page);
+        }
+        memset(ntup_buf, 0, ntup_size);
+        ((hnsw_ntup *)ntup_buf)->type_ = 2;
+        if (blk != nblk || pg_page_add_item(page, ntup_buf, ntup_size) != noff) goto done;
+    }
+    uint32_t insert_page = blk;
+    /* write_neighbor_tuples */
+    for (int idx = 0; idx < x->n; idx++) {
+        const elem_t *el = &x->el[idx];
+        if (el->merged) continue;
+        size_t ntup_size = pg_maxalign(sizeof(hnsw_ntup) + (size_t)(el->level + 2) * x->m * sizeof(pg_tid));
+        memset(ntup_buf, 0, ntup_size);
+        hnsw_ntup *nt = (hnsw_ntup *)ntup_buf; nt->type_ = 2; nt->version = 0;
+        pg_tid *tids = (pg_tid *)(ntup_buf + sizeof(hnsw_ntup));
+        int k = 0;
+        for (int lc = el->level; lc >= 0; lc--) {
+            int lm = layer_m(x->m, lc);
+            for (int i = 0; i < lm; i++, k++) {
+                if (i < el->ncnt[lc]) { const disk_loc *nl = &locs[el->nbr[lc][i].idx]; pg_tid_set(&tids[k], nl->blkno, nl->offno); }
+                else pg_tid_invalid(&tids[k]);
+            }
+        }
+        nt->count = (uint16_t)k;
+        if (!pg_page_overwrite(pages + (size_t)locs[idx].neighbor_page * PG_BLCKSZ, locs[idx].neighbor_offno, ntup_buf, ntup_size)) goto done;
+    }
+    /* update_meta_page */
+    if (x->entry >= 0) { meta->entry_blkno = locs[x->entry].blkno; meta->entry_offno = locs[x->entry].offno; meta->entry_level = (int16_t)x->el[x->entry].level; }
+    meta->insert_page = insert_page;
+    for (int i = 0; i < x->n; i++) { if (blk_out) blk_out[i] = locs[i].blkno; if (off_out) off_out[i] = locs[i].offno; }
+    result = (uint64_t)blk + 1;
+done:
+    free(locs); free(etup_buf); free(ntup_buf);
+    return result;
+}
+
 /* exact brute force top-k (ground truth for recall; distances in the index's order) */
 ORC_API int orc_bruteforce_topk(orc_index *x, const void *query, int k, int *ids, double *dist)
 {

@@ -72,6 +72,7 @@ def lib():
             "orc_scan_next": (i32, [vp, vp, vp, vp]),
             "orc_search_topk": (i32, [vp, vp, i32, i32, vp, vp]),
             "orc_search_many": (None, [vp, vp, i32, i32, i32, i32, vp, vp]),
+            "orc_index_write_pages": (C.c_uint64, [vp, vp, C.c_uint64, vp, vp]),
             "orc_bruteforce_topk": (i32, [vp, vp, i32, vp, vp]),
             "orc_distances_many": (None, [i32, i32, i32, vp, vp, vp, i32, i32, vp]),
             "orc_pairwise": (None, [i32, i32, i32, vp, vp, i32, i32, vp]),
@@ -285,6 +286,19 @@ class Index:
         cnt = np.zeros(nq, np.int32)
         lib().orc_search_many(self.h, _p(q), nq, ef_search, k, int(n_threads), _p(ids), _p(cnt))
         return ids, cnt
+
+    def write_pages(self, cap_pages=None):
+        """The index as PostgreSQL HNSW pages (build.rs:545-821): (pages uint8 [n_pages, 8192], blkno[n], offno[n])."""
+        n = self.size
+        if cap_pages is None:
+            cap_pages = 2 + 2 * n + 2
+        pages = np.zeros((cap_pages, 8192), np.uint8)
+        blk = np.zeros(max(n, 1), np.uint32)
+        off = np.zeros(max(n, 1), np.uint16)
+        got = lib().orc_index_write_pages(self.h, _p(pages), cap_pages, _p(blk), _p(off))
+        if got == 0:
+            raise RuntimeError("orc_index_write_pages failed (tuple too large / capacity / add failure)")
+        return pages[:got].copy(), blk[:n], off[:n]
 
     def bruteforce_topk(self, query, k):
         q = as_rows(self.dtype, query)

@@ -87,6 +87,7 @@ def lib():
         "hx_index_fused_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
         "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
+        "hx_index_serialize_pages": (i32, [vp, vp, u64, C.POINTER(u64), vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
@@ -360,6 +361,17 @@ class Index:
         return {"advance_s": p[0], "compact_s": p[1], "fill_s": p[2], "round_s": p[3], "rounds": int(p[5]), "fused_s": p[6],
                 "mirror_sync_s": p[7], "links_setup_s": p[8], "links_lockstep_s": p[9], "insert_total_s": p[10],
                 "batch_search_s": p[11], "batch_begin_s": p[12], "links_max_chain": int(p[13]), "links_ops": int(p[14])}
+
+    def serialize_pages(self):
+        """hx_index_serialize_pages: (pages uint8 [n_pages, 8192], elem_blkno[n], elem_offno[n])."""
+        n = self.size
+        npg = C.c_uint64()
+        self._ck(lib().hx_index_serialize_pages(self.h, None, 0, C.byref(npg), None, None))
+        pages = np.zeros((npg.value, 8192), np.uint8)
+        blk = np.zeros(max(n, 1), np.uint32)
+        off = np.zeros(max(n, 1), np.uint16)
+        self._ck(lib().hx_index_serialize_pages(self.h, _p(pages), npg.value, C.byref(npg), _p(blk), _p(off)))
+        return pages, blk[:n], off[:n]
 
     def set_fused(self, on):
         self._ck(lib().hx_index_set_fused(self.h, int(on)))

@@ -1259,4 +1259,158 @@ int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int
     return search_impl(ix, nq, ef_search, mode, max_scan_tuples, limit, filter_pass, n_filter, tids_out, dist_out, nullptr, counts_out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// f1: graph -> PostgreSQL HNSW index pages.  One forward pass over the elements: a cursor (current block, its
+// pd_lower / pd_upper) places the element tuple and then the neighbour tuple exactly where PageAddItemExtended would
+// (line pointer grows from the front, MAXALIGNed tuple data from the back); since every element's location is known
+// only after the pass, neighbour TIDs are filled in a second sweep over the already-placed tuples (the reference
+// overwrites its placeholders the same way, build.rs:727-795).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t PG_BLCKSZ = HX_PAGE_SIZE, PG_PAGE_HDR = 24, PG_ITEMID = 4, PG_SPECIAL = 8, PG_LAYOUT_VERSION = 4;
+constexpr uint32_t ETUP_HDR = 72, NTUP_HDR = 4, TID_BYTES = 6, INVALID_BLOCK = 0xFFFFFFFFu;
+inline uint32_t pg_maxalign(uint32_t x) { return (x + 7u) & ~7u; }
+inline void put16(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+inline void put32(uint8_t *p, uint32_t v) { put16(p, v & 0xffffu); put16(p + 2, v >> 16); }
+inline void put_tid(uint8_t *p, uint32_t blk, uint32_t off) { put16(p, blk >> 16); put16(p + 2, blk & 0xffffu); put16(p + 4, off); }   // ItemPointerSet: bi_hi, bi_lo, ip_posid
+struct PageCursor {
+    uint8_t *base; uint64_t cap; uint32_t blk; uint32_t lower, upper;
+    uint8_t *page() const { return base ? base + (size_t)blk * PG_BLCKSZ : nullptr; }
+    bool start(uint32_t b)                     // PageInit(page, BLCKSZ, sizeof(HnswPageOpaqueData)) + hnsw_init_page, build.rs:59-65
+    {
+        blk = b; lower = PG_PAGE_HDR; upper = PG_BLCKSZ - PG_SPECIAL;
+        if (!base) return true;
+        if (b >= cap) return false;
+        uint8_t *pg = page();
+        memset(pg, 0, PG_BLCKSZ);
+        put16(pg + 12, lower); put16(pg + 14, upper); put16(pg + 16, upper); put16(pg + 18, PG_BLCKSZ | PG_LAYOUT_VERSION);
+        put32(pg + upper, INVALID_BLOCK); put16(pg + upper + 4, 0); put16(pg + upper + 6, 0xFF90);
+        return true;
+    }
+    uint32_t free_space() const { const uint32_t sp = upper - lower; return sp < PG_ITEMID ? 0u : sp - PG_ITEMID; }   // PageGetFreeSpace
+    uint32_t max_off() const { return (lower - PG_PAGE_HDR) / PG_ITEMID; }                                              // PageGetMaxOffsetNumber
+    // PageAddItemExtended(page, item, size, InvalidOffsetNumber, 0): returns the tuple's byte offset in the page, 0 if it does not fit
+    uint32_t add(uint32_t size)
+    {
+        const uint32_t nl = lower + PG_ITEMID, al = pg_maxalign(size);
+        if (al > upper || nl > upper - al) return 0;
+        const uint32_t nu = upper - al;
+        if (base) {
+            uint8_t *pg = page();
+            put32(pg + lower, nu | (1u << 15) | (size << 17));           // ItemIdSetNormal: lp_off:15 | lp_flags=LP_NORMAL:2 | lp_len:15
+            put16(pg + 12, nl); put16(pg + 14, nu);
+        }
+        lower = nl; upper = nu;
+        return nu;
+    }
+    void link_next(uint32_t next) { if (base) put32(page() + (PG_BLCKSZ - PG_SPECIAL), next); }                          // hnsw_build_append_page, build.rs:92-112
+};
+}  // namespace
+
+int hx_index_serialize_pages(const hx_index *cix, uint8_t *pages_out, uint64_t cap_pages, uint64_t *n_pages_out,
+                             uint32_t *elem_blkno_out, uint16_t *elem_offno_out)
+{
+    if (!cix || !n_pages_out) return HX_E_ARG;
+    hx_index *ix = const_cast<hx_index *>(cix);
+    const Graph &g = ix->g;
+    const hx_engine *e = ix->e;
+    const uint32_t n = g.size(), m = (uint32_t)g.m;
+    const uint32_t payload = (uint32_t)hx_row_bytes(e), value_size = 8u + payload;
+    const uint32_t max_size = PG_BLCKSZ - pg_maxalign(PG_PAGE_HDR) - pg_maxalign(PG_SPECIAL) - PG_ITEMID;               // hnsw_max_size, types/hnsw.rs:325-331
+    const uint32_t etup_size = pg_maxalign(ETUP_HDR + value_size);                                                         // hnsw_element_tuple_size
+    if (etup_size > max_size) return ix->fail(HX_E_ARG, "index tuple too large");                                          // build.rs:611-613
+    if (pages_out && cap_pages < 2) return ix->fail(HX_E_ARG, "cap_pages too small");
+
+    struct Loc { uint32_t blk, nblk; uint16_t off, noff; uint32_t nbyte; };   // element tuple (blk, off); neighbour tuple (nblk, noff) at byte nbyte of its page
+    std::vector<Loc> loc(n, Loc{INVALID_BLOCK, INVALID_BLOCK, 0, 0, 0});
+    std::vector<uint8_t> rows;                                                // payload of a chunk of elements, read back from the device
+    const uint32_t CH = 16384; uint32_t rows_first = 0, rows_n = 0;
+
+    // ---- meta page (block 0), create_meta_page build.rs:545-568 ----
+    PageCursor cur{pages_out, cap_pages, 0, 0, 0};
+    if (!cur.start(0)) return ix->fail(HX_E_ARG, "cap_pages too small");
+    uint8_t *meta = pages_out ? pages_out + PG_PAGE_HDR : nullptr;
+    if (meta) {
+        put32(meta + 0, 0xA953A953u); put32(meta + 4, 1u); put32(meta + 8, (uint32_t)e->dim);
+        put16(meta + 12, m); put16(meta + 14, (uint32_t)ix->efc);
+        put32(meta + 16, INVALID_BLOCK); put16(meta + 20, 0); put16(meta + 22, 0xFFFFu /* entry_level -1 */); put32(meta + 24, INVALID_BLOCK);
+        put16(pages_out + 12, PG_PAGE_HDR + 28u);                                                                          // pd_lower = end of HnswMetaPageData
+    }
+    // ---- data pages, create_graph_pages build.rs:576-712 ----
+    if (!cur.start(1)) return ix->fail(HX_E_ARG, "cap_pages too small");
+    for (uint32_t idx = 0; idx < n; idx++) {
+        if (g.level[idx] < 0) continue;                                                                                    // merged duplicate: no element of its own
+        const uint32_t level = (uint32_t)g.level[idx];
+        if (level > 255u) return ix->fail(HX_E_STATE, "level does not fit the element tuple");
+        const uint32_t ntup_size = pg_maxalign(NTUP_HDR + (level + 2u) * m * TID_BYTES);                                   // hnsw_neighbor_tuple_size
+        const uint32_t combined = etup_size + ntup_size + PG_ITEMID;
+        uint32_t fs = cur.free_space();
+        if (fs < etup_size || (combined <= max_size && fs < combined)) {                                                   // build.rs:644-650
+            cur.link_next(cur.blk + 1);
+            if (!cur.start(cur.blk + 1)) return ix->fail(HX_E_ARG, "cap_pages too small");
+        }
+        Loc &L = loc[idx];
+        L.blk = cur.blk; L.off = (uint16_t)(cur.max_off() + 1);
+        if (combined <= max_size) { L.nblk = L.blk; L.noff = (uint16_t)(L.off + 1); } else { L.nblk = L.blk + 1; L.noff = 1; }   // build.rs:657-661
+        const uint32_t eb = cur.add(etup_size);
+        if (!eb) return ix->fail(HX_E_STATE, "failed to add element tuple to page");
+        if (pages_out) {
+            if (idx < rows_first || idx >= rows_first + rows_n) {
+                rows_first = idx; rows_n = std::min<uint32_t>(CH, n - idx);
+                rows.resize((size_t)rows_n * payload);
+                int rc = hx_read_rows(ix->e, rows_first, rows_n, rows.data());
+                if (rc) return ix->fail(rc, hx_last_error(ix->e));
+            }
+            uint8_t *t = cur.page() + eb;                              // page was zeroed: padding and `unused` stay 0
+            t[0] = 1; t[1] = (uint8_t)level; t[2] = 0; t[3] = 0;
+            for (uint32_t k = 0; k < HEAPTIDS; k++) {
+                if (k < g.ntids[idx]) { const uint64_t v = (uint64_t)g.tids[idx][k]; put_tid(t + 4 + k * TID_BYTES, (uint32_t)(v >> 16), (uint32_t)(v & 0xffffu)); }
+                else put_tid(t + 4 + k * TID_BYTES, INVALID_BLOCK, 0);                                                     // ItemPointerSetInvalid
+            }
+            put_tid(t + 64, L.nblk, L.noff);
+            uint8_t *v = t + ETUP_HDR;
+            put32(v, value_size << 2);                                                                                     // SET_VARSIZE, 4-byte header
+            if (e->dtype == HX_BIT) put32(v + 4, (uint32_t)e->dim); else { put16(v + 4, (uint32_t)e->dim); put16(v + 6, 0); }
+            memcpy(v + 8, rows.data() + (size_t)(idx - rows_first) * payload, payload);
+        }
+        if (cur.free_space() < ntup_size) {                                                                                // build.rs:684-688
+            cur.link_next(cur.blk + 1);
+            if (!cur.start(cur.blk + 1)) return ix->fail(HX_E_ARG, "cap_pages too small");
+        }
+        if (cur.blk != L.nblk || cur.max_off() + 1 != L.noff) return ix->fail(HX_E_STATE, "failed to add neighbor tuple to page");
+        L.nbyte = cur.add(ntup_size);
+        if (!L.nbyte) return ix->fail(HX_E_STATE, "failed to add neighbor tuple to page");
+    }
+    const uint32_t insert_page = cur.blk, n_pages = cur.blk + 1;
+    *n_pages_out = n_pages;
+    for (uint32_t i = 0; i < n; i++) { if (elem_blkno_out) elem_blkno_out[i] = loc[i].blk; if (elem_offno_out) elem_offno_out[i] = loc[i].off; }
+    if (!pages_out) return HX_OK;
+    // ---- neighbour tuples, write_neighbor_tuples build.rs:719-795 ----
+    for (uint32_t idx = 0; idx < n; idx++) {
+        if (g.level[idx] < 0) continue;
+        const Loc &L = loc[idx];
+        uint8_t *t = pages_out + (size_t)L.nblk * PG_BLCKSZ + L.nbyte;
+        t[0] = 2; t[1] = 0;
+        uint32_t k = 0;
+        for (int lc = g.level[idx]; lc >= 0; lc--) {
+            const uint32_t lm = (uint32_t)g.lm(lc), c = g.cnt(idx, lc); const Cand *lst = g.list(idx, lc);
+            for (uint32_t i = 0; i < lm; i++, k++) {
+                if (i < c) {
+                    const Loc &N = loc[lst[i].id];
+                    if (N.blk == INVALID_BLOCK) return ix->fail(HX_E_STATE, "neighbour list references a merged duplicate");
+                    put_tid(t + NTUP_HDR + k * TID_BYTES, N.blk, N.off);
+                } else put_tid(t + NTUP_HDR + k * TID_BYTES, INVALID_BLOCK, 0);
+            }
+        }
+        put16(t + 2, k);
+    }
+    // ---- update_meta_page build.rs:801-821 ----
+    if (g.entry >= 0) {
+        const Loc &E = loc[(size_t)g.entry];
+        put32(meta + 16, E.blk); put16(meta + 20, E.off); put16(meta + 22, (uint32_t)g.level[(size_t)g.entry] & 0xffffu);
+    }
+    put32(meta + 24, insert_page);
+    return HX_OK;
+}
+
 } // extern "C"
