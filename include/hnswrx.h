@@ -235,7 +235,8 @@ int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int
  * Page 0 is the meta page, data pages follow; every page is HX_PAGE_SIZE bytes (BLCKSZ 8192, layout version 4).
  * The value varlena is rebuilt from the engine's payload: {vl_len_ = size << 2, dim:i16, unused:i16} for
  * vector / halfvec (vector.rs:43-48, halfvec.rs:41-46), {vl_len_, bit_len:i32} for bit (bitvec.rs:28-37).
- * Heap TIDs: the int64 tids given to hx_index_insert are read as (block << 16) | offset.
+ * Heap TIDs: the int64 tids given to hx_index_insert are read as (block << 16) | offset; offsets start at 1
+ * (FirstOffsetNumber) -- offset 0 is PostgreSQL's invalid TID and reads back as "no TID".
  * Tombstoned duplicates (merged into another element's heap TIDs) get no tuples, as in build.rs:482-512.
  *   pages_out == NULL: only computes *n_pages_out (and the element locations, if asked);
  *   else writes min(cap_pages, needed) pages and fails with HX_E_ARG when cap_pages is too small.
@@ -244,6 +245,22 @@ int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int
 #define HX_PAGE_SIZE 8192
 int hx_index_serialize_pages(const hx_index *ix, uint8_t *pages_out, uint64_t cap_pages, uint64_t *n_pages_out,
                              uint32_t *elem_blkno_out, uint16_t *elem_offno_out);
+
+/* ---- PostgreSQL index pages -> engine (the scan side's (blkno, offno) -> row map) -----------
+ * The inverse of hx_index_serialize_pages, and what a scan-side host does once per index: walks the page chain from
+ * HNSW_HEAD_BLKNO (block 1), reads element tuples the way load_element does (type 1, not deleted, payload at
+ * etup + 72, heap TIDs up to the first invalid one: scan.rs:155-228) and neighbour tuples the way load_neighbor_tids
+ * does (version / count check, layer slots at 4 + ((level - layer) * m + i) * 6, up to the first invalid TID:
+ * scan.rs:236-283), appends the payloads to the (empty) engine in (block, offset) order -- element index == row id ==
+ * order of appearance -- and rebuilds the graph, heap TIDs ((block << 16) | offset) and the entry point of the meta
+ * page.  Deleted elements are not loaded and TIDs that point at them are dropped (the scan skips them the same way).
+ * The page format stores no distances; they are recomputed with the batched distance kernel, so a loaded index is
+ * indistinguishable from the one that was serialised (same bits), and inserts may continue on it.
+ * Requires an empty index on an empty engine whose dtype/dim match the stored varlenas and whose m matches the meta
+ * page.  elem_blkno_out / elem_offno_out (nullable, capacity `cap_elems`): the (blkno, offno) -> row map, by row;
+ * *n_elems_out = elements loaded. */
+int hx_index_load_pages(hx_index *ix, const uint8_t *pages, uint64_t n_pages, uint32_t *elem_blkno_out, uint16_t *elem_offno_out,
+                        uint64_t cap_elems, uint64_t *n_elems_out);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,7 @@ def lib():
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
         "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
         "hx_index_serialize_pages": (i32, [vp, vp, u64, C.POINTER(u64), vp, vp]),
+        "hx_index_load_pages": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
@@ -372,6 +373,16 @@ class Index:
         off = np.zeros(max(n, 1), np.uint16)
         self._ck(lib().hx_index_serialize_pages(self.h, _p(pages), npg.value, C.byref(npg), _p(blk), _p(off)))
         return pages, blk[:n], off[:n]
+
+    def load_pages(self, pages):
+        """hx_index_load_pages: fills the (empty) index and engine from a page image; returns (elem_blkno, elem_offno)."""
+        pages = np.ascontiguousarray(pages, np.uint8).reshape(-1, 8192)
+        cap = len(pages) * 400          # an 8 KB page holds fewer than 400 element tuples
+        blk = np.zeros(max(cap, 1), np.uint32)
+        off = np.zeros(max(cap, 1), np.uint16)
+        n = C.c_uint64()
+        self._ck(lib().hx_index_load_pages(self.h, _p(pages), len(pages), _p(blk), _p(off), cap, C.byref(n)))
+        return blk[:n.value], off[:n.value]
 
     def set_fused(self, on):
         self._ck(lib().hx_index_set_fused(self.h, int(on)))

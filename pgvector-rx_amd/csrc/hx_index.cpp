@@ -1413,4 +1413,150 @@ int hx_index_serialize_pages(const hx_index *cix, uint8_t *pages_out, uint64_t c
     return HX_OK;
 }
 
+// f2: pages -> graph + rows (see include/hnswrx.h).  Reads are bounds-checked: a malformed image yields HX_E_ARG, never a fault.
+namespace {
+inline uint32_t get16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t get32(const uint8_t *p) { return get16(p) | (get16(p + 2) << 16); }
+struct TidRef { uint32_t blk, off; bool valid() const { return !(blk == INVALID_BLOCK) && off != 0; } };   // ItemPointerIsValid: ip_posid != 0
+inline TidRef get_tid(const uint8_t *p) { return TidRef{(get16(p) << 16) | get16(p + 2), get16(p + 4)}; }
+}
+
+int hx_index_load_pages(hx_index *ix, const uint8_t *pages, uint64_t n_pages, uint32_t *elem_blkno_out, uint16_t *elem_offno_out,
+                        uint64_t cap_elems, uint64_t *n_elems_out)
+{
+    if (!ix || !pages || !n_elems_out) return HX_E_ARG;
+    Graph &g = ix->g; hx_engine *e = ix->e;
+    if (g.size() != 0 || hx_num_rows(e) != 0) return ix->fail(HX_E_STATE, "hx_index_load_pages needs an empty index on an empty engine");
+    if (n_pages < 2 || n_pages > 0xFFFFFFFEull) return ix->fail(HX_E_ARG, "page image too short");
+    const uint8_t *meta = pages + PG_PAGE_HDR;
+    if (get32(meta) != 0xA953A953u || get32(meta + 4) != 1u) return ix->fail(HX_E_ARG, "not an HNSW meta page (magic / version)");
+    const uint32_t m = get16(meta + 12);
+    if (get32(meta + 8) != (uint32_t)e->dim) return ix->fail(HX_E_ARG, "meta page dimensions differ from the engine's");
+    if (m != (uint32_t)g.m) return ix->fail(HX_E_ARG, "meta page m differs from the index's");
+    const uint32_t payload = (uint32_t)hx_row_bytes(e), value_size = 8u + payload;
+    // item table of every page on the chain: (page, offset number) -> byte offset, length
+    auto item = [&](uint32_t blk, uint32_t off, uint32_t &lo, uint32_t &ln) -> bool {
+        if (blk == 0 || blk >= n_pages || off == 0) return false;
+        const uint8_t *pg = pages + (size_t)blk * PG_BLCKSZ;
+        const uint32_t lower = get16(pg + 12);
+        if (lower < PG_PAGE_HDR || lower > PG_BLCKSZ || off > (lower - PG_PAGE_HDR) / PG_ITEMID) return false;
+        const uint32_t lp = get32(pg + PG_PAGE_HDR + (off - 1) * PG_ITEMID);
+        lo = lp & 0x7fffu; ln = lp >> 17;
+        return ((lp >> 15) & 3u) == 1u && ln != 0 && lo + ln <= PG_BLCKSZ;          // LP_NORMAL, scan.rs:170-174
+    };
+    // pass 1: elements in chain order
+    struct El { uint32_t blk, off, lo; };
+    std::vector<El> els;
+    std::vector<uint32_t> page_base(n_pages + 1, 0u);                              // index into item_idx
+    for (uint64_t b = 0; b < n_pages; b++) {
+        const uint32_t lower = get16(pages + b * PG_BLCKSZ + 12);
+        page_base[b + 1] = page_base[b] + (b == 0 || lower < PG_PAGE_HDR || lower > PG_BLCKSZ ? 0u : (lower - PG_PAGE_HDR) / PG_ITEMID);
+    }
+    std::vector<uint32_t> item_idx(page_base[n_pages], 0xFFFFFFFFu);
+    {
+        std::vector<uint8_t> seen(n_pages, 0);
+        for (uint32_t blk = 1; blk != INVALID_BLOCK;) {
+            if (blk >= n_pages || seen[blk]) return ix->fail(HX_E_ARG, "page chain leaves the image or loops");
+            seen[blk] = 1;
+            const uint8_t *pg = pages + (size_t)blk * PG_BLCKSZ;
+            const uint32_t special = get16(pg + 16);
+            if (special != PG_BLCKSZ - PG_SPECIAL || get16(pg + special + 6) != 0xFF90u) return ix->fail(HX_E_ARG, "not an HNSW page (special area / page id)");
+            const uint32_t nitems = page_base[blk + 1] - page_base[blk];
+            for (uint32_t off = 1; off <= nitems; off++) {
+                uint32_t lo, ln;
+                if (!item(blk, off, lo, ln)) continue;
+                const uint8_t *t = pg + lo;
+                if (t[0] != 1 || t[2] != 0) continue;                              // element tuples that are not deleted, scan.rs:178-181
+                if (ln < ETUP_HDR + value_size || (get32(t + ETUP_HDR) >> 2) != value_size) return ix->fail(HX_E_ARG, "element value size differs from the engine's row size");
+                item_idx[page_base[blk] + off - 1] = (uint32_t)els.size();
+                els.push_back(El{blk, off, lo});
+            }
+            blk = get32(pg + special);
+        }
+    }
+    const uint32_t n = (uint32_t)els.size();
+    if ((elem_blkno_out || elem_offno_out) && cap_elems < n) return ix->fail(HX_E_ARG, "cap_elems too small");
+    auto lookup = [&](const TidRef &t) -> uint32_t {
+        if (!t.valid() || t.blk >= n_pages) return 0xFFFFFFFFu;
+        if (t.off > page_base[t.blk + 1] - page_base[t.blk]) return 0xFFFFFFFFu;
+        return item_idx[page_base[t.blk] + t.off - 1];
+    };
+    // rows
+    {
+        const uint32_t CH = 16384; std::vector<uint8_t> buf((size_t)std::min(CH, std::max(n, 1u)) * payload);
+        for (uint32_t i0 = 0; i0 < n; i0 += CH) {
+            const uint32_t c = std::min(CH, n - i0);
+            for (uint32_t i = 0; i < c; i++) memcpy(buf.data() + (size_t)i * payload, pages + (size_t)els[i0 + i].blk * PG_BLCKSZ + els[i0 + i].lo + ETUP_HDR + 8, payload);
+            uint64_t first = 0;
+            int rc = hx_append_rows(e, buf.data(), c, &first);
+            if (rc) return ix->fail(rc, hx_last_error(e));
+        }
+    }
+    // graph
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t *t = pages + (size_t)els[i].blk * PG_BLCKSZ + els[i].lo;
+        const int level = t[1];
+        g.add(level);
+        uint8_t nt = 0;
+        for (uint32_t k = 0; k < HEAPTIDS; k++) {
+            const TidRef h = get_tid(t + 4 + k * TID_BYTES);
+            if (!h.valid()) break;                                                 // scan.rs:201-207
+            g.tids[i][nt++] = (int64_t)(((uint64_t)h.blk << 16) | h.off);
+        }
+        g.ntids[i] = nt;
+        const TidRef nref = get_tid(t + 64);
+        uint32_t lo, ln;
+        if (!item(nref.blk, nref.off, lo, ln)) continue;
+        const uint8_t *nt_ = pages + (size_t)nref.blk * PG_BLCKSZ + lo;
+        if (nt_[0] != 2 || nt_[1] != t[3] || get16(nt_ + 2) != (uint32_t)(level + 2) * m || ln < NTUP_HDR + (uint32_t)(level + 2) * m * TID_BYTES) continue;   // scan.rs:262-266
+        for (int lc = level; lc >= 0; lc--) {
+            const uint32_t lm = (uint32_t)g.lm(lc), start = (uint32_t)(level - lc) * m;
+            Cand *lst = g.list(i, lc); uint16_t c = 0;
+            for (uint32_t k = 0; k < lm; k++) {
+                const TidRef r = get_tid(nt_ + NTUP_HDR + (start + k) * TID_BYTES);
+                if (!r.valid()) break;                                             // scan.rs:275-277
+                const uint32_t id = lookup(r);
+                if (id == 0xFFFFFFFFu) continue;                                   // deleted / stale target: load_element would return None
+                lst[c++] = Cand{0.0f, id};
+            }
+            g.cnt(i, lc) = c;
+        }
+        if (elem_blkno_out) elem_blkno_out[i] = els[i].blk;
+        if (elem_offno_out) elem_offno_out[i] = (uint16_t)els[i].off;
+    }
+    for (uint32_t i = 0; i < n && (elem_blkno_out || elem_offno_out); i++) { if (elem_blkno_out) elem_blkno_out[i] = els[i].blk; if (elem_offno_out) elem_offno_out[i] = (uint16_t)els[i].off; }
+    const TidRef ent{get32(meta + 16), get16(meta + 20)};
+    const uint32_t ent_idx = lookup(ent);
+    g.entry = ent_idx == 0xFFFFFFFFu ? -1 : (int64_t)ent_idx;
+    // distances of every list, batched through K1 (query = the element's own row)
+    {
+        const uint32_t GCH = 1u << 18;
+        std::vector<uint32_t> gq, goff, gids; std::vector<std::pair<uint32_t, int>> gl; std::vector<float> out;
+        auto flush = [&]() -> int {
+            if (gq.empty()) return HX_OK;
+            out.resize(gids.size());
+            int rc = hx_distances_batch(e, (uint32_t)gq.size(), gq.data(), goff.data(), gids.data(), out.data());
+            if (rc) return ix->fail(rc, hx_last_error(e));
+            for (size_t k = 0; k < gl.size(); k++) { Cand *lst = g.list(gl[k].first, gl[k].second); for (uint32_t j = goff[k]; j < goff[k + 1]; j++) lst[j - goff[k]].d = out[j]; }
+            gq.clear(); goff.assign(1, 0u); gids.clear(); gl.clear();
+            return HX_OK;
+        };
+        goff.assign(1, 0u);
+        for (uint32_t i = 0; i < n; i++) {
+            for (int lc = g.level[i]; lc >= 0; lc--) {
+                const uint16_t c = g.cnt(i, lc); if (!c) continue;
+                const Cand *lst = g.list(i, lc);
+                gq.push_back(i); gl.emplace_back(i, lc);
+                for (uint16_t k = 0; k < c; k++) gids.push_back(lst[k].id);
+                goff.push_back((uint32_t)gids.size());
+                ix->dirty.emplace_back(i, lc);
+            }
+            if (gq.size() >= GCH) { int rc = flush(); if (rc) return rc; }
+        }
+        int rc = flush(); if (rc) return rc;
+    }
+    *n_elems_out = n;
+    return HX_OK;
+}
+
 } // extern "C"

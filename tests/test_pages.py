@@ -9,6 +9,12 @@ from oracle import orc
 from tests import pgpages
 
 
+def heap_tids(n, first=0):
+    """Heap TIDs as (block << 16) | offset with offsets from FirstOffsetNumber = 1 (offset 0 is PostgreSQL's invalid TID)."""
+    i = np.arange(first, first + n, dtype=np.int64)
+    return ((i // 64) << 16) | (i % 64 + 1)
+
+
 def make_rows(dtype, dim, n, m, seed, dup_every=0):
     rng = np.random.default_rng(seed)
     if dtype == orc.BIT:
@@ -153,3 +159,110 @@ def test_engine_pages_equal_oracle_pages(dtype, metric, dim, n, m, dup, batch):
     assert np.array_equal(gblk, wblk) and np.array_equal(goff, woff)
     assert np.array_equal(got, want)
     check_against_graph(x, rows, got, gblk, goff, m, efc, dim, dtype)
+
+
+def _same_index(a, b, n):
+    assert a.size == b.size == n and a.entry == b.entry
+    for i in range(n):
+        assert a.level(i) == b.level(i)
+        assert list(a.heaptids(i)) == list(b.heaptids(i))
+        for l in range(max(a.level(i), -1) + 1):
+            ia, da = a.neighbors(i, l)
+            ib, db = b.neighbors(i, l)
+            assert np.array_equal(ia, ib) and np.array_equal(da.view(np.uint32), db.view(np.uint32))   # recomputed distances: same bits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,metric,dim,n,m,batch", [
+    (orc.F32, orc.L2SQ, 16, 600, 8, 32),
+    (orc.F32, orc.NEG_IP, 200, 300, 16, 8),
+    (orc.F16, orc.L2SQ, 10, 300, 6, 8),
+    (orc.BIT, orc.HAMMING, 52, 400, 5, 16),
+])
+def test_load_pages_round_trip_then_keep_inserting(dtype, metric, dim, n, m, batch):
+    """serialize -> load into a fresh engine gives the same index (ids, heap TIDs, distance bits), the same scans, the same
+    pages again; and inserting more rows afterwards gives the same graph as inserting them into the original."""
+    import pgvector_rx_amd as hx
+    extra = 64
+    rows, levels = make_rows(dtype, dim, n + extra, m, 13)
+    efc = max(24, 2 * m)
+    e1 = hx.Engine(dtype, metric, dim, n + extra); e1.append(rows[:n])
+    a = hx.Index(e1, m, efc); a.insert(0, levels[:n], heap_tids(n), batch=batch)
+    pages, blk, off = a.serialize_pages()
+    e2 = hx.Engine(dtype, metric, dim, n + extra)
+    b = hx.Index(e2, m, efc)
+    lblk, loff = b.load_pages(pages)
+    assert np.array_equal(lblk, blk) and np.array_equal(loff, off)          # no duplicates here: element i == row i on both sides
+    _same_index(a, b, n)
+    q = rows[n:n + 20]
+    e1.set_queries(q); e2.set_queries(q)
+    ra, rb = a.search(20, 16, 5), b.search(20, 16, 5)
+    for u, v in zip(ra, rb):
+        assert np.array_equal(u, v)
+    again, _, _ = b.serialize_pages()
+    assert np.array_equal(again, pages)
+    e1.append(rows[n:]); e2.append(rows[n:])
+    a.insert(n, levels[n:], heap_tids(extra, n), batch=16); b.insert(n, levels[n:], heap_tids(extra, n), batch=16)
+    _same_index(a, b, n + extra)
+
+
+@pytest.mark.gpu
+def test_load_pages_written_by_the_oracle_with_popped_duplicates_and_a_deleted_element():
+    """Pages as the CPU path writes them (sequential build, duplicates merged into heap TIDs and popped): the loaded index
+    answers scans exactly as the oracle scans its own graph; an element flagged deleted is skipped like load_element does."""
+    import pgvector_rx_amd as hx
+    dim, n, m = 12, 300, 6
+    rows, levels = make_rows(orc.F32, dim, n, m, 21, dup_every=9)
+    x = orc.Index(orc.F32, orc.L2SQ, dim, m=m, ef_construction=24, order=orc.W64)
+    ht = heap_tids(n)
+    for i in range(n):
+        x.insert(rows[i], int(levels[i]), int(ht[i]))
+    pages, blk, off = x.write_pages()
+    eng = hx.Engine(orc.F32, orc.L2SQ, dim, n)
+    ix = hx.Index(eng, m, 24)
+    lb, lo = ix.load_pages(pages)
+    assert ix.size == x.size < n                                             # merged rows were popped
+    rng = np.random.default_rng(5)
+    qs = rng.random((15, dim), dtype=np.float32)
+    eng.set_queries(qs)
+    tids, d, el, cnt = ix.search(15, 24, 6)
+    for q in range(15):
+        ids, dist = x.search_topk(qs[q], 24, 6)
+        # k counts heap tuples, and an element that absorbed duplicates returns several: compare element by element
+        got_el = [int(v) for j, v in enumerate(el[q, :cnt[q]]) if j == 0 or v != el[q, j - 1]]
+        want_el = [int(v) for j, v in enumerate(ids) if j == 0 or v != ids[j - 1]]      # the oracle's scan also yields one entry per heap tuple
+        assert got_el == want_el and cnt[q] == len(ids)
+        for j in range(cnt[q]):
+            assert int(tids[q, j]) in x.tids(int(el[q, j]))
+    # flag one non-entry element deleted in the image: it disappears from the loaded graph
+    victim = next(i for i in range(x.size) if i != x.entry and x.level(i) == 0)
+    pg = pages.copy()
+    its = pgpages.items(bytes(pg[blk[victim]]))
+    pg[blk[victim], its[off[victim] - 1][0] + 2] = 1
+    eng2 = hx.Engine(orc.F32, orc.L2SQ, dim, n)
+    ix2 = hx.Index(eng2, m, 24)
+    ix2.load_pages(pg)
+    assert ix2.size == x.size - 1
+
+
+@pytest.mark.gpu
+def test_load_pages_rejects_malformed_images():
+    import pgvector_rx_amd as hx
+    x, rows, _ = build_oracle(orc.F32, orc.L2SQ, 8, 50, 4, 24, 2)
+    pages, _, _ = x.write_pages()
+    def fresh(dim=8, m=4):
+        e = hx.Engine(orc.F32, orc.L2SQ, dim, 64)
+        return e, hx.Index(e, m, 24)
+    bad = pages.copy(); bad[0, 24] ^= 0xFF                                   # magic
+    with pytest.raises(hx.HxError):
+        fresh()[1].load_pages(bad)
+    with pytest.raises(hx.HxError):
+        fresh(dim=9)[1].load_pages(pages)                                    # dimensions
+    with pytest.raises(hx.HxError):
+        fresh(m=5)[1].load_pages(pages)                                      # m
+    with pytest.raises(hx.HxError):
+        fresh()[1].load_pages(pages[:-1])                                    # chain leaves the image
+    e, ix = fresh()
+    ix.load_pages(pages)
+    with pytest.raises(hx.HxError):
+        ix.load_pages(pages)                                                 # not empty any more
