@@ -407,3 +407,77 @@ def test_fused_equals_lockstep_at_scale():
     assert (np.abs(a[1][:, 0] - chk) <= 1e-5 * chk).all()
     ix.close()
     e.close()
+
+
+@pytest.mark.gpu
+def test_full_size_c2_structural_properties():
+    """BASELINE configs[1] at its full size (1M x vector(768), m=16, ef_construction=200), where the oracle cannot follow:
+    size-independent properties of the reference's graph and scan --
+      * every list respects its bound (2m at layer 0, m above: hnsw_get_layer_m), holds valid, distinct, non-self ids of elements
+        that reach that layer, and its stored distances are the exact distance bits of (owner, neighbour);
+      * level histogram equals the drawn levels, the entry point is a top-level element (build.rs:516-525);
+      * scan results come back sorted, distances within 1e-5 of an f64 recomputation, recall@10 vs exact brute force as bench.py
+        reports it; scanning twice is idempotent; the lock-step placement returns the same tids and distance bits for a query sample."""
+    import torch
+    n, dim, m, efc, efs, k, nq = 1_000_000, 768, 16, 200, 100, 10, 2000
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    cen = torch.rand((1024, dim), generator=g, device="cuda")
+    rows = torch.empty((n, dim), device="cuda")
+    for i in range(0, n, 1 << 17):
+        j = min(n, i + (1 << 17))
+        rows[i:j] = cen[torch.randint(0, 1024, (j - i,), generator=g, device="cuda")] + 0.1 * torch.randn((j - i, dim), generator=g, device="cuda")
+    qs = cen[torch.randint(0, 1024, (nq,), generator=g, device="cuda")] + 0.1 * torch.randn((nq, dim), generator=g, device="cuda")
+    torch.cuda.synchronize()
+    levels = hx.draw_levels(n, m, seed=11)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+    e.append_device(rows.data_ptr(), n)
+    ix = hx.Index(e, m, efc)
+    ix.insert(0, levels, batch=8192)
+    assert ix.size == n and ix.fused_stats()["redone"] == 0
+    lv = ix.export_levels()
+    assert np.array_equal(lv, levels)                                   # no duplicates in this data: nothing tombstoned
+    top = int(lv.max())
+    assert lv[ix.entry] == top
+    rng = np.random.default_rng(1)
+    for layer in range(top + 1):
+        ids, dist, cnt = ix.export_layer(layer)
+        lm = 2 * m if layer == 0 else m
+        owners = np.nonzero(lv >= layer)[0]
+        c = cnt[owners].astype(np.int64)
+        assert (c <= lm).all() and (cnt[lv < layer] == 0).all()
+        if layer == 0:
+            assert (c >= 1).all()                                        # every element is linked at layer 0
+        valid = np.arange(lm)[None, :] < c[:, None]
+        idv, dv = ids[owners], dist[owners]
+        assert (idv[valid] < n).all() and (lv[idv[valid]] >= layer).all()
+        assert not (idv == owners[:, None])[valid].any()                 # no self links
+        srt = np.sort(np.where(valid, idv, np.uint32(0xFFFFFFFF)), axis=1)
+        dup = (srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] != 0xFFFFFFFF)
+        assert not dup.any()                                             # distinct neighbours
+        # stored distances: exact bits of d(owner, neighbour) from the batched kernel, for a sample of lists
+        pick = owners[rng.integers(0, len(owners), min(2000, len(owners)))]
+        goff = np.concatenate([[0], np.cumsum(cnt[pick].astype(np.int64))]).astype(np.uint32)
+        gids = np.concatenate([ids[p, :cnt[p]] for p in pick]).astype(np.uint32)
+        fresh = e.distances_batch(pick.astype(np.uint32), goff, gids)
+        stored = np.concatenate([dist[p, :cnt[p]] for p in pick])
+        assert np.array_equal(fresh.view(np.uint32), stored.view(np.uint32))
+    # scans
+    e.set_queries_device(qs.data_ptr(), nq)
+    a = ix.search(nq, efs, k)
+    b = ix.search(nq, efs, k)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)                                      # idempotent
+    assert (a[3] == k).all() and (np.diff(a[1], axis=1) >= 0).all()
+    rn = (rows * rows).sum(1)
+    gt = torch.cat([torch.topk(rn[None, :] - 2.0 * qs[i:i + 250] @ rows.T, k, dim=1, largest=False).indices for i in range(0, nq, 250)]).cpu().numpy()
+    recall = np.mean([len(set(a[0][q].tolist()) & set(gt[q].tolist())) / k for q in range(nq)])
+    assert recall >= 0.95, recall
+    near = torch.from_numpy(a[0][:, 0].astype(np.int64)).cuda()
+    chk = ((rows[near].double() - qs.double()) ** 2).sum(1).cpu().numpy()
+    assert (np.abs(a[1][:, 0] - chk) <= 1e-5 * chk).all()
+    ix.set_fused(False)
+    e.set_queries_device(qs.data_ptr(), 200)
+    c2 = ix.search(200, efs, k)
+    assert np.array_equal(c2[0], a[0][:200]) and np.array_equal(c2[1].view(np.uint32), a[1][:200].view(np.uint32))
+    ix.close()
+    e.close()
