@@ -41,6 +41,11 @@ struct FusedParams {
     uint32_t *next_task;
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
+    // iterative scan (k_fused MODE 2): hnsw.iterative_scan relaxed_order (1) / strict_order (2), scan.rs:794-875
+    uint32_t iter_mode, limit; long long max_tuples;
+    const uint16_t *emask;                        // per element: bits 0-9 = which of its heap TIDs pass the filter, bits 12-15 = number of heap TIDs
+    unsigned long long *disc; uint32_t disc_stride, disc_lds;   // per-workgroup tail of the `discarded` heap (entries), its LDS head
+    uint32_t *out_tix;                            // which heap TID of the element each output is
     float *dsc;                                   // 64 floats of LDS scratch for the short-row distance path (set inside the kernels)
     uint32_t fdbg;                                // experiments (HX_F_DBG): 1 no pre-filter, 4 phase timers into n_dist[3..7]
 };
@@ -113,54 +118,83 @@ template <bool NEAREST> struct FHeap {
 //     same path is again one ballot, and all the moves are one store.
 // The resulting array is the one the serial algorithm leaves, element for element (ties included).
 #define F_WSYNC() asm volatile("" ::: "memory")     /* LDS ops of one wave execute in order; only the compiler must not reorder */
+// heap storage for PHeap: plain LDS, or an LDS head + a tail in this workgroup's global area (the `discarded` heap of an
+// iterative scan holds every visited element that is not a result: tens of thousands of entries).  The global part is read
+// and written with L1-bypassing 64-bit accesses because different lanes of the wave read what other lanes wrote.
+struct LStore {
+    lds_uint2 *A;
+    static constexpr bool kGlobal = false;
+    __device__ __forceinline__ uint2 ld(uint32_t i) const { return make_uint2(A[i].x, A[i].y); }
+    __device__ __forceinline__ void st(uint32_t i, uint2 v) const { A[i].x = v.x; A[i].y = v.y; }
+};
+struct GStore {
+    lds_uint2 *A; unsigned long long *G; uint32_t L;
+    static constexpr bool kGlobal = true;
+    __device__ __forceinline__ uint2 ld(uint32_t i) const
+    {
+        if (i < L) return make_uint2(A[i].x, A[i].y);
+        const unsigned long long v = __hip_atomic_load(G + (i - L), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    }
+    __device__ __forceinline__ void st(uint32_t i, uint2 v) const
+    {
+        if (i < L) { A[i].x = v.x; A[i].y = v.y; }
+        else __hip_atomic_store(G + (i - L), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
 template <bool NEAREST> struct PHeap {
     static __device__ __forceinline__ bool le(float a, float b) { return NEAREST ? !(b > a) : !(a > b); }
     static __device__ __forceinline__ uint2 ld(lds_uint2 *A, uint32_t i) { return make_uint2(A[i].x, A[i].y); }
-    static __device__ __forceinline__ void st(lds_uint2 *A, uint32_t i, uint2 v) { A[i].x = v.x; A[i].y = v.y; }
-    static __device__ __forceinline__ void push(lds_uint2 *A, uint32_t &len, uint2 c, uint32_t lane)
+    template <class ST> static __device__ __forceinline__ void sync(const ST &)
+    {   // LDS ops of one wave execute in order; global stores must have landed before another lane reads them back
+        if (ST::kGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else F_WSYNC();
+    }
+    template <class ST> static __device__ __forceinline__ void push(const ST &S, uint32_t &len, uint2 c, uint32_t lane)
     {
-        F_WSYNC();
+        sync(S);
         const uint32_t pos1 = len + 1u; len++;                         // 1-based slot of the new element
         const uint32_t depth = 31u - (uint32_t)__builtin_clz(pos1);    // number of ancestors
         const bool anc = lane >= 1u && lane <= depth;                  // lane k holds the k-th ancestor
         uint2 v = make_uint2(0u, 0u);
-        if (anc) v = ld(A, (pos1 >> lane) - 1u);
+        if (anc) v = S.ld((pos1 >> lane) - 1u);
         const unsigned long long sm = __ballot(anc && le(fh_d(c), fh_d(v)));   // sift_up breaks at the first such ancestor
         const uint32_t t = sm ? (uint32_t)__builtin_ctzll(sm) : depth + 1u;
-        if (anc && lane < t) st(A, (pos1 >> (lane - 1u)) - 1u, v);     // ancestors below the stop move down one level
-        if (lane == 0u) st(A, (pos1 >> (t - 1u)) - 1u, c);
-        F_WSYNC();
+        if (anc && lane < t) S.st((pos1 >> (lane - 1u)) - 1u, v);      // ancestors below the stop move down one level
+        if (lane == 0u) S.st((pos1 >> (t - 1u)) - 1u, c);
+        sync(S);
     }
-    static __device__ __forceinline__ uint2 pop(lds_uint2 *A, uint32_t &len, uint32_t lane)   // len > 0
+    template <class ST> static __device__ __forceinline__ uint2 pop(const ST &S, uint32_t &len, uint32_t lane)   // len > 0
     {
-        F_WSYNC();
-        const uint2 last = ld(A, len - 1u); len--;
+        sync(S);
+        const uint2 last = S.ld(len - 1u); len--;
         if (len == 0u) return last;
-        const uint2 top = ld(A, 0u);
+        const uint2 top = S.ld(0u);
         const uint32_t end = len;
         uint32_t pos = 0u, child = 1u, k = 0u;
         uint32_t myP = 0u, myC = 0u; uint2 myV = make_uint2(0u, 0u);   // lane k: path slot k, path slot k+1 and its old value
         while (end >= 2u && child <= end - 2u) {
-            const uint2 a = ld(A, child), b = ld(A, child + 1u);
+            const uint2 a = S.ld(child), b = S.ld(child + 1u);
             const bool right = le(fh_d(a), fh_d(b));
             const uint2 cv = right ? b : a; const uint32_t cp = child + (right ? 1u : 0u);
             if (lane == k) { myP = pos; myC = cp; myV = cv; }
             pos = cp; child = 2u * pos + 1u; k++;
         }
         if (child == end - 1u) {
-            const uint2 a = ld(A, child);
+            const uint2 a = S.ld(child);
             if (lane == k) { myP = pos; myC = child; myV = a; }
             k++;
         }
         // the moved element climbs back from the bottom of the path while it beats its parent: it ends in path slot t
         const unsigned long long sm = __ballot(lane < k && le(fh_d(last), fh_d(myV)));
         const uint32_t t = sm ? 64u - (uint32_t)__builtin_clzll(sm) : 0u;
-        if (lane < t) st(A, myP, myV);
-        if (t == 0u) { if (lane == 0u) st(A, 0u, last); }
-        else if (lane == t - 1u) st(A, myC, last);
-        F_WSYNC();
+        if (lane < t) S.st(myP, myV);
+        if (t == 0u) { if (lane == 0u) S.st(0u, last); }
+        else if (lane == t - 1u) S.st(myC, last);
+        sync(S);
         return top;
     }
+    static __device__ __forceinline__ void push(lds_uint2 *A, uint32_t &len, uint2 c, uint32_t lane) { push(LStore{A}, len, c, lane); }
+    static __device__ __forceinline__ uint2 pop(lds_uint2 *A, uint32_t &len, uint32_t lane) { return pop(LStore{A}, len, lane); }
 };
 
 // visited set (HashSet<usize> of graph/mod.rs:171): a per-workgroup open-addressing table of row ids in global memory
@@ -206,6 +240,7 @@ __device__ __forceinline__ bool vis_test_and_set(uint32_t *tab, uint32_t bmask, 
 struct FusedCtx {
     uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
+    GStore DS; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
     uint32_t tph[13];  // diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
 };
@@ -334,15 +369,26 @@ __device__ __forceinline__ bool f_any_le(const FusedParams &p, const uint8_t *qv
 // Algorithm 2 with entry points EP[0..n_ep); leaves the result set in the W heap (cx.CTL[1] = |W|).
 // scan == false: search_layer (graph/mod.rs:161-255); scan == true: search_layer_disk without `discarded` (scan.rs:302-448).
 #define F_TICK(k) do { if (tm) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); cx.tph[k] += (uint32_t)(t1_ - t0); t0 = t1_; } } while (0)
-template <class OP, int LPR>
-__device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan)
+// ITER: search_layer_disk WITH the iterative scan's state (scan.rs:302-448): the visited set is the caller's and survives
+// resumes (fresh == false keeps it; eps_visited == false: resume_scan_items' entry points are already in it), and every
+// visited element that does not end in W goes to the `discarded` min-heap, in the reference's order of pushes.
+template <class OP, int LPR, bool ITER = false>
+__device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
 {
     const uint32_t lane = cx.lane;
-    // fresh visited set
-    for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
-    uint32_t vcount = n_ep;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(p.vis_words >> 2) - 1u, cx.EP[i].y);
+    if (fresh) {   // fresh visited set
+        for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    uint32_t vcount = fresh ? 0u : cx.vcount;
+    if (eps_visited) {
+        vcount += n_ep;
+        for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(p.vis_words >> 2) - 1u, cx.EP[i].y);
+    }
+    auto d_push = [&](uint2 it) {
+        if (cx.dlen >= p.disc_stride + p.disc_lds) { cx.status = FS_OVERFLOW; return; }
+        PHeap<true>::push(cx.DS, cx.dlen, it, lane);
+    };
     // heaps are driven by the whole wave (PHeap) while the candidate heap fits its LDS part; a heap that outgrows it
     // (rare) is handed to the serial hybrid LDS+spill code on lane 0.  clen/wl/rlen: |C|, |W|, result_len -- wave-uniform.
     uint32_t clen = 0, wl = 0, rlen = 0;
@@ -389,9 +435,10 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             e_first = lane < lmax ? nb[lane] : 0u;                                   // issued together with the count: one memory hop
             if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
         }
-        if (clen > 0) (void)c_pop();                                                 // mod.rs:187 (the popped element is the root read above)
+        uint2 popped = make_uint2(0u, 0u); const bool had = clen > 0;
+        if (had) popped = c_pop();                                                   // mod.rs:187 (the popped element is the root read above)
         F_TICK(0);
-        if (!go) break;
+        if (!go) { if (ITER && had) d_push(popped); break; }                         // scan.rs:341-345
         if (tm) cx.tph[7]++;
         // a linked element at layer 0 always has level >= 0, so the check of mod.rs:198-200 needs no load there
         if (layer > 0 && clevel < layer) continue;
@@ -429,7 +476,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
                 const float f0 = __builtin_bit_cast(float, (unsigned int)WA[0].x);
                 keep = scan ? !((double)mine >= (double)f0) : (mine < f0);
             }
-            unsigned long long km = __ballot(keep);
+            unsigned long long km = ITER ? __ballot(lane < cnt) : __ballot(keep);     // ITER: rejected rows are visited too (they go to `discarded`)
             F_TICK(5);
             __syncthreads();
             while (km) {                                                             // replay in list order, mod.rs:226-243 / scan.rs:372-429
@@ -440,18 +487,25 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
                 bool add;
                 if (!scan) { const float f = wl ? wtop : 3.402823466e+38f; add = d < f || always_add; }
                 else { const double f = wl ? (double)wtop : 1.7976931348623157e+308; add = !(!always_add && (double)d >= f); }
-                if (!add) continue;
+                if (!add) { if (ITER) { d_push(it); if (cx.status != FS_OK) break; } continue; }   // scan.rs:385-404
                 if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
                 c_push(it); PHeap<false>::push(WA, wl, it, lane); rlen++;
                 if (tm) cx.tph[8]++;
                 if (clen > cx.cmax) cx.cmax = clen;
-                if (rlen > ef) { (void)PHeap<false>::pop(WA, wl, lane); rlen--; }
+                if (rlen > ef) {
+                    const uint2 ev = PHeap<false>::pop(WA, wl, lane); rlen--;
+                    if (ITER) { d_push(ev); if (cx.status != FS_OK) break; }        // scan.rs:423-428
+                }
             }
             __syncthreads();
             F_TICK(6);
             cx.status = __shfl(cx.status, 0, 64);
             if (cx.status != FS_OK) break;
         }
+    }
+    if (ITER) {
+        while (clen > 0 && cx.status == FS_OK) d_push(c_pop());                      // scan.rs:432-438: what is left of C
+        cx.vcount = vcount;
     }
     if (lane == 0) cx.CTL[1] = wl;
     __syncthreads();
@@ -492,6 +546,8 @@ k_fused(const FusedParams p_in)
     cx.CTL = cx.IDS + 64;
     p.dsc = (float *)(cx.CTL + 16);
     cx.QV = (uint8_t *)(p.dsc + 64);                      // query parked in LDS (nch KiB)
+    cx.DS.A = (lds_uint2 *)(cx.QV + p.nch * 1024u); cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
+    cx.DS.G = MODE == 2 ? p.disc + (size_t)blockIdx.x * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
     cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
     cx.CH.lds = (lds_uint2 *)cx.C; cx.CH.glob = p.spill + (size_t)blockIdx.x * p.spill_stride; cx.CH.L = p.clds;
@@ -527,16 +583,69 @@ k_fused(const FusedParams p_in)
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
         const int stop_above = MODE == 1 ? new_level : 0;
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
-            f_search_layer<OP, LPR>(p, cx, n_ep, 1u, lc, MODE == 0);
+            f_search_layer<OP, LPR>(p, cx, n_ep, 1u, lc, MODE != 1);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
-                f_sort_results(cx, wl, MODE == 0);
-                if (MODE == 0) { const uint2 best = cx.EP[wl - 1]; __syncthreads(); if (lane == 0) cx.EP[0] = best; __syncthreads(); }
+                f_sort_results(cx, wl, MODE != 1);
+                if (MODE != 1) { const uint2 best = cx.EP[wl - 1]; __syncthreads(); if (lane == 0) cx.EP[0] = best; __syncthreads(); }
                 n_ep = 1;                         // MODE 1: ep = vec![w[0]]; EP[0] already is the nearest
-            } else if (MODE == 0) { n_ep = 0; break; }
+            } else if (MODE != 1) { n_ep = 0; break; }
         }
 
-        if (MODE == 0) {
+        if (MODE == 2) {
+            // get_scan_items + the amgettuple loop of an iterative scan (scan.rs:458-577, 794-875) for one query
+            uint32_t outc = 0; long long tuples = 0; double prev = -__builtin_inf();
+            cx.dlen = 0; cx.vcount = 0;
+            const size_t obase = (size_t)t * p.limit;
+            if (cx.status == FS_OK && n_ep > 0) {
+                f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, true, true);           // scan.rs:515-528
+                bool single = false;
+                for (;;) {
+                    if (cx.status != FS_OK) break;
+                    const uint32_t wl = single ? 1u : cx.CTL[1];
+                    if (!single) f_sort_results(cx, wl, true);                                   // EP[0..wl): nearest LAST
+                    // emit from the back (scan.rs:796-815, 860-874); the elements' TID masks are fetched 64 at a time
+                    uint32_t left = wl;
+                    while (left > 0 && outc < p.limit) {
+                        const uint32_t c = left < 64u ? left : 64u, base = left - c;
+                        if (lane < c) cx.IDS[lane] = p.emask[cx.EP[base + lane].y];
+                        __syncthreads();
+                        for (uint32_t i = c; i-- > 0 && outc < p.limit;) {
+                            const uint32_t em = cx.IDS[i]; const uint32_t nt = em >> 12;
+                            if (nt == 0) continue;                                               // scan.rs:866-868
+                            tuples++;
+                            const uint2 v = cx.EP[base + i]; const double dv = (double)fh_d(v);
+                            for (int ti = (int)nt - 1; ti >= 0 && outc < p.limit; ti--) {        // heaptids.pop()
+                                if (p.iter_mode == 2u) { if (dv < prev) continue; prev = dv; }   // strict_order, scan.rs:801-806
+                                if (!((em >> ti) & 1u)) continue;                                // the executor's filter rejects this tuple
+                                if (lane == 0) { p.out_ids[obase + outc] = v.y; p.out_d[obase + outc] = fh_d(v); p.out_tix[obase + outc] = (uint32_t)ti; }
+                                outc++;
+                            }
+                        }
+                        __syncthreads();
+                        left = base;
+                    }
+                    if (outc >= p.limit) break;
+                    if (tuples >= p.max_tuples) {                                                // scan.rs:831-841: drain `discarded` one by one
+                        if (cx.dlen == 0) break;
+                        const uint2 one = PHeap<true>::pop(cx.DS, cx.dlen, lane);
+                        __syncthreads(); if (lane == 0) cx.EP[0] = one; __syncthreads();
+                        single = true;
+                        continue;
+                    }
+                    if (cx.dlen == 0) break;                                                     // resume_scan_items, scan.rs:548-550
+                    single = false;
+                    n_ep = 0;
+                    while (n_ep < p.ef && cx.dlen > 0) {
+                        const uint2 x = PHeap<true>::pop(cx.DS, cx.dlen, lane);
+                        __syncthreads(); if (lane == 0) cx.EP[n_ep] = x; __syncthreads();
+                        n_ep++;
+                    }
+                    f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, false, false);
+                }
+            }
+            if (lane == 0) { p.out_cnt[t] = outc; p.status[t] = cx.status; }
+        } else if (MODE == 0) {
             uint32_t cnt = 0;
             if (cx.status == FS_OK && n_ep > 0) {
                 f_search_layer<OP, LPR>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
@@ -1171,6 +1280,7 @@ static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid
 template <class OP, int LPR>
 static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
 {
+    if (mode == 2) return launch_fused<OP, 2, LPR>(e, p, grid, lds);
     return mode == 0 ? launch_fused<OP, 0, LPR>(e, p, grid, lds) : launch_fused<OP, 1, LPR>(e, p, grid, lds);
 }
 template <class OP>
@@ -1185,12 +1295,13 @@ static hipError_t launch_fused_mode(hx_engine *e, const FusedParams &p, uint32_t
 // [ntasks][FUSED_MAXL][2m], out_cnt [ntasks][FUSED_MAXL].  status[ntasks].  All host pointers.
 int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                          uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                         uint64_t counts[2])
+                         uint64_t counts[2], const HxFusedIter *it)
 {
     HxMirror &mr = mirror;
     if (ntasks == 0) return HX_OK;
     if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_ARG, "row too wide for the fused kernel");
     if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
+    if (mode == 2 && (!it || !it->emask || !it->out_tix)) return fail(HX_E_ARG, "iterative scan arguments missing");
     HX_HIP(this, hipSetDevice(device));
     // LDS: C[ccap] W[ef+2] EP[ef+2] RES[64] RL[2m] DL[ef+2] (8 B each) + IDS[64] + CTL[16] (4 B each)
     // candidate heap: up to FUSED_CCAP entries, the first `clds` in LDS and the tail in a per-workgroup spill area
@@ -1199,26 +1310,50 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t nch_ = (pitch + 1023) / 1024;
     const uint32_t ccap = FUSED_CCAP;
     uint32_t clds = mode == 1 ? 1024u : 512u;
+    const uint32_t disc_lds = mode == 2 ? 256u : 0u;
     { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
     clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024; };
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024 + (size_t)disc_lds * 8; };
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
-    const uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
+    uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
     uint64_t vis_words = 4096; while (vis_words < (uint64_t)ef * 2 * mr.m * 2 + 1024) vis_words <<= 1;   // >= 2x the ids a search can touch at its usual ~ef expansions
+    uint64_t disc_stride = 0;
+    if (mode == 2) {
+        // an iterative scan keeps its visited set and `discarded` heap across resumes: sized for max_scan_tuples (a query that
+        // outgrows them reports FS_OVERFLOW and is re-run by the lock-step path); fewer resident workgroups bound the footprint
+        const uint64_t mt = (uint64_t)std::min<long long>(std::max<long long>(it->max_tuples, 1), 1 << 20);
+        disc_stride = std::max<uint64_t>(4 * mt, 16384);
+        while (vis_words < 8 * mt + 4096) vis_words <<= 1;
+        grid = std::min<uint32_t>(grid, 256u * 8u);
+        const size_t need_disc = (size_t)256 * 8 * disc_stride * 8;
+        if (need_disc > mr.cap_disc) {
+            if (mr.d_disc) (void)hipFree(mr.d_disc);
+            mr.d_disc = nullptr; mr.cap_disc = 0;
+            HX_HIP(this, hipMalloc((void **)&mr.d_disc, need_disc));
+            mr.cap_disc = need_disc;
+        }
+        if (mr.cap > mr.cap_emask) {
+            if (mr.d_emask) (void)hipFree(mr.d_emask);
+            mr.d_emask = nullptr; mr.cap_emask = 0;
+            HX_HIP(this, hipMalloc((void **)&mr.d_emask, (size_t)mr.cap * 2));
+            mr.cap_emask = mr.cap;
+        }
+        HX_HIP(this, hipMemcpyAsync(mr.d_emask, it->emask, (size_t)it->n_elems * 2, hipMemcpyHostToDevice, stream));
+    }
     if (!mr.d_spill) HX_HIP(this, hipMalloc((void **)&mr.d_spill, (size_t)256 * 16 * FUSED_CCAP * 8));
     if ((uint64_t)grid * vis_words > mr.cap_vis) {
         if (mr.d_vis) (void)hipFree(mr.d_vis);
         mr.d_vis = nullptr; mr.cap_vis = 0;
-        const uint64_t n = (uint64_t)256 * 16 * vis_words;
+        const uint64_t n = (uint64_t)(mode == 2 ? grid : 256u * 16u) * vis_words;
         HX_HIP(this, hipMalloc((void **)&mr.d_vis, n * 4));
         mr.cap_vis = n;
     }
-    const size_t out_n = mode == 0 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;
-    const size_t cnt_n = mode == 0 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
+    const size_t out_n = mode != 1 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;      // mode 2: k = limit
+    const size_t cnt_n = mode != 1 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
     // device task/in/out buffers (one allocation, reused)
-    const size_t need = al16((size_t)ntasks * 4) * 3 + al16(out_n * 4) * 2 + al16(cnt_n * 4) + 256;
+    const size_t need = al16((size_t)ntasks * 4) * 3 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
     if (need > mr.cap_io) {
         if (mr.d_io) (void)hipFree(mr.d_io);
         if (mr.h_io) (void)hipHostFree(mr.h_io);
@@ -1237,6 +1372,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t o_cnt = o; o += al16(cnt_n * 4);
     const size_t o_ids = o; o += al16(out_n * 4);
     const size_t o_d = o; o += al16(out_n * 4);
+    const size_t o_tix = o; o += al16(out_n * 4);
     memset(mr.h_io + o_ctr, 0, 256);
     memcpy(mr.h_io + o_q, q_sel, (size_t)ntasks * 4);
     if (t_level) memcpy(mr.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(mr.h_io + o_lv, 0, (size_t)ntasks * 4);
@@ -1247,6 +1383,8 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     p.m = mr.m; p.entry = entry; p.entry_level = entry_level;
     p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(mr.d_io + o_q); p.t_level = (const int32_t *)(mr.d_io + o_lv);
     p.ef = ef; p.k = k; p.ccap = ccap; p.clds = clds;
+    p.iter_mode = 0; p.limit = k; p.max_tuples = 0; p.emask = nullptr; p.disc = nullptr; p.disc_stride = 0; p.disc_lds = disc_lds; p.out_tix = (uint32_t *)(mr.d_io + o_tix);
+    if (mode == 2) { p.iter_mode = (uint32_t)it->iter_mode; p.max_tuples = it->max_tuples; p.emask = mr.d_emask; p.disc = (unsigned long long *)mr.d_disc; p.disc_stride = (uint32_t)disc_stride; }
     p.spill = (uint2 *)mr.d_spill; p.spill_stride = FUSED_CCAP;
     { const char *dv = getenv("HX_F_DBG"); p.fdbg = dv ? (uint32_t)atoi(dv) : 0u; }
     p.vis = mr.d_vis; p.vis_words = vis_words;
@@ -1270,6 +1408,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
     memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
     memcpy(out_d, mr.h_io + o_d, out_n * 4);
+    if (mode == 2) memcpy(it->out_tix, mr.h_io + o_tix, out_n * 4);
     unsigned long long nd[16]; memcpy(nd, mr.h_io + o_ctr + 8, 128);
     if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))
         fprintf(stderr, "[hx] k_fused mode %d tasks %u: 100 MHz ticks summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu\n",

@@ -1212,6 +1212,43 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
         }
         ix->fused_tasks += nq; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
+    } else if (mode != 0 && ix->fused_ok() && ix->g.entry >= 0 && limit <= 4096) {
+        // iterative scan on the device (k_fused MODE 2): the filter reaches the kernel as a per-element mask of passing heap TIDs
+        int rc = ix->sync_mirror();
+        if (rc) return rc;
+        const Graph &g = ix->g;
+        const uint32_t n = g.size();
+        std::vector<uint16_t> emask(n);
+        ix->pool->parallel_for((n + 65535) / 65536, [&](size_t ci) {
+            for (size_t el = ci * 65536; el < std::min<size_t>(n, ci * 65536 + 65536); el++) {
+                const uint32_t nt = g.level[el] < 0 ? 0u : g.ntids[el]; uint32_t msk = 0;
+                for (uint32_t t = 0; t < nt; t++) { const int64_t tid = g.tids[el][t]; if (!filter || (tid >= 0 && (uint64_t)tid < n_filter && filter[tid])) msk |= 1u << t; }
+                emask[el] = (uint16_t)(msk | (nt << 12));
+            }
+        });
+        std::vector<uint32_t> qsel(nq), status(nq), ocnt(nq), oids((size_t)nq * limit), otix((size_t)nq * limit);
+        std::vector<float> od((size_t)nq * limit);
+        for (uint32_t q = 0; q < nq; q++) qsel[q] = HX_QUERY_SLOT | q;
+        HxFusedIter it; it.iter_mode = mode; it.max_tuples = max_scan_tuples; it.emask = emask.data(); it.n_elems = n; it.out_tix = otix.data();
+        uint64_t cnts[2] = {0, 0};
+        auto t0 = std::chrono::steady_clock::now();
+        if ((rc = ix->e->fused_run(2, nq, qsel.data(), nullptr, ef_search, limit, (uint32_t)g.entry, g.level[g.entry],
+                                   oids.data(), od.data(), ocnt.data(), status.data(), cnts, &it))) return ix->fail(rc, ix->e->err);
+        ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ix->counters[4] += cnts[0];
+        for (uint32_t q = 0; q < nq; q++) {
+            if (status[q] != 0) { todo.push_back(q); continue; }
+            const uint32_t c = std::min(ocnt[q], limit);
+            for (uint32_t i = 0; i < c; i++) {
+                const uint32_t el = oids[(size_t)q * limit + i];
+                tids_out[(size_t)q * limit + i] = g.tids[el][otix[(size_t)q * limit + i]];
+                if (dist_out) dist_out[(size_t)q * limit + i] = od[(size_t)q * limit + i];
+                if (elems_out) elems_out[(size_t)q * limit + i] = el;
+            }
+            counts_out[q] = c;
+        }
+        ix->fused_tasks += nq; ix->fused_redo += todo.size();
+        if (todo.empty()) return HX_OK;
     } else {
         for (uint32_t q = 0; q < nq; q++) todo.push_back(q);
     }

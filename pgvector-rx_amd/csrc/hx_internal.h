@@ -46,8 +46,17 @@ struct HxMirror {
     float *d_pm = nullptr; uint8_t *d_pm_valid = nullptr; uint64_t cap_pm = 0;   // resident pair matrices of the layer-0 lists
     uint32_t *d_vis = nullptr; uint64_t cap_vis = 0;
     void *d_spill = nullptr;                 // candidate-heap spill areas of the fused kernel's workgroups
+    void *d_disc = nullptr; size_t cap_disc = 0;             // `discarded` heaps of iterative scans (k_fused MODE 2)
+    uint16_t *d_emask = nullptr; uint64_t cap_emask = 0;     // per-element heap-TID filter masks of the current iterative scan
     uint8_t *h_stage = nullptr, *d_stage = nullptr; size_t cap_stage = 0;
     uint8_t *h_io = nullptr, *d_io = nullptr; size_t cap_io = 0;
+};
+
+// arguments of an iterative scan on the device (k_fused MODE 2)
+struct HxFusedIter {
+    int iter_mode = 1; long long max_tuples = 0;       // 1 relaxed_order, 2 strict_order; hnsw.max_scan_tuples
+    const uint16_t *emask = nullptr; uint64_t n_elems = 0;   // per element: bits 0-9 heap TIDs that pass the filter, bits 12-15 number of heap TIDs
+    uint32_t *out_tix = nullptr;                       // [ntasks][limit]: which heap TID of out_ids' element
 };
 
 struct hx_engine {
@@ -79,7 +88,7 @@ struct hx_engine {
                   const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs);
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                  uint64_t counts[2]);
+                  uint64_t counts[2], const HxFusedIter *it = nullptr);
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 

@@ -481,3 +481,37 @@ def test_full_size_c2_structural_properties():
     assert np.array_equal(c2[0], a[0][:200]) and np.array_equal(c2[1].view(np.uint32), a[1][:200].view(np.uint32))
     ix.close()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,metric,dim,n", [(hx.F32, hx.L2SQ, 8, 6000), (hx.BIT, hx.HAMMING, 64, 5000), (hx.F16, hx.NEG_IP, 24, 4000)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_iterative_scan_on_device_equals_lockstep_and_oracle(dt, metric, dim, n, mode):
+    """Iterative scans run inside k_fused (MODE 2: visited set and `discarded` heap kept across resumes on the device).  Same
+    tids, same distance bits as the lock-step host driver, and the oracle's tids -- Hamming included, where equal distances
+    make the order of pushes into `discarded` visible."""
+    rng = np.random.default_rng(7)
+    m, efc = 8, 32
+    rows = make_rows(dt, n, dim, rng)
+    levels = hx.draw_levels(n, m, seed=7)
+    e, ix, _, o, _ = build_both(dt, metric, dim, rows, levels, m, efc, 64)
+    nq, efs, limit = 40, 20, 9
+    qs = make_rows(dt, nq, dim, rng)
+    e.set_queries(qs)
+    for c, max_tuples in [(1, 20000), (40, 20000), (40, 150), (700, 20000), (3, 1)]:
+        passes = (np.arange(n) % c == 0).astype(np.uint8)
+        before = ix.fused_stats()
+        ix.set_fused(True)
+        a = ix.search_iterative(nq, efs, mode, max_tuples, limit, passes)
+        after = ix.fused_stats()
+        assert after["tasks"] == before["tasks"] + nq and after["redone"] == before["redone"]     # served by the device kernel
+        ix.set_fused(False)
+        b = ix.search_iterative(nq, efs, mode, max_tuples, limit, passes)
+        ix.set_fused(True)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), (c, max_tuples)
+        it = orc.ITER_RELAXED if mode == 1 else orc.ITER_STRICT
+        for q in range(0, nq, 5):
+            want = [t for t, x, _ in o.scan(qs[q], ef_search=efs, iterative=it, max_scan_tuples=max_tuples) if passes[t]][:limit]
+            assert a[0][q, :a[2][q]].tolist() == want, (c, max_tuples, q)
+    ix.close()
+    e.close()

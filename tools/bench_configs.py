@@ -9,6 +9,7 @@ c5: N x bit(1024) Hamming, plain scan + iterative_scan=relaxed_order with a 1 % 
 Prints one JSON line: build seconds, QPS, recall@10 vs exact brute force (torch), kernel roofline figures.
 """
 import json
+import os
 import sys
 import time
 
@@ -75,7 +76,7 @@ def run(name, n, data="baseline"):
         gt_fn = lambda: topk_chunks(lambda a, b: qs[a:b].float() @ rows.float().T if n <= 200_000 else (qs[a:b] @ rows.T).float(), nq, n, k, True)
     elif name == "c5":
         n = n or 2_000_000
-        dim, m, efc, efs, dt, mt, nq = 1024, 16, 64, 40, hx.BIT, hx.HAMMING, 2000
+        dim, m, efc, efs, dt, mt, nq = 1024, 16, 64, 40, hx.BIT, hx.HAMMING, int(os.environ.get("HX_C5_QUERIES", "2000"))
         rows = torch.randint(0, 256, (n, dim // 8), generator=g, device=DEV, dtype=torch.uint8)
         qs = torch.randint(0, 256, (nq, dim // 8), generator=g, device=DEV, dtype=torch.uint8)
         if data == "clustered":        # 4096 random centre patterns, every bit flipped with probability 1/8 (AND of three random bytes)
@@ -133,17 +134,19 @@ def run(name, n, data="baseline"):
            "fused": ix.fused_stats(), "host_profile": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ix.profile().items()}}
     if iterative:
         passes = (np.arange(n) % iterative["filter_every"] == 0).astype(np.uint8)
-        nqi = 500
+        nqi = int(os.environ.get("HX_ITER_QUERIES", "500"))
+        ix.profile(reset=True)
         t0 = time.perf_counter()
         it_tids, it_d, it_cnt = ix.search_iterative(nqi, efs, iterative["mode"], iterative["max_scan_tuples"], iterative["limit"], passes)
         it_s = time.perf_counter() - t0
+        it_prof = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ix.profile().items() if k in ("advance_s", "compact_s", "fill_s", "round_s", "rounds")}
         # exact answer under the filter
         sub = torch.nonzero(torch.from_numpy(passes).to(DEV)).squeeze(1)
         sc = (bits_pm1(qs[:nqi]) @ rpm[sub].T).float()
         gti = sub[torch.topk(sc, k, dim=1).indices].cpu().numpy()
         out["iterative_relaxed"] = {"queries": nqi, "filter": "tid %% %d == 0" % iterative["filter_every"], "max_scan_tuples": iterative["max_scan_tuples"],
                                     "qps": round(nqi / it_s, 1), "recall_at_10": round(recall(it_tids, it_cnt, gti, k), 4),
-                                    "mean_returned": float(it_cnt.mean()), "path": "lock-step host driver (discarded heap)"}
+                                    "mean_returned": float(it_cnt.mean()), "path": "k_fused MODE 2 (device-resident iterative scan); lock-step host driver when set_fused(False)", "host_profile": it_prof}
     print(json.dumps(out), flush=True)
 
 
