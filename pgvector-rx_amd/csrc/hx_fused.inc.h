@@ -146,8 +146,9 @@ template <bool NEAREST> struct PHeap {
     static __device__ __forceinline__ bool le(float a, float b) { return NEAREST ? !(b > a) : !(a > b); }
     static __device__ __forceinline__ uint2 ld(lds_uint2 *A, uint32_t i) { return make_uint2(A[i].x, A[i].y); }
     template <class ST> static __device__ __forceinline__ void sync(const ST &)
-    {   // LDS ops of one wave execute in order; global stores must have landed before another lane reads them back
-        if (ST::kGlobal) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else F_WSYNC();
+    {   // LDS ops of one wave execute in order, and so do its vector-memory ops to one address at the L2 both sides go to
+        // (L1 bypassed): wavefront-scope ordering needs no wait on gfx9 (LLVM AMDGPU memory model), only a compiler barrier
+        F_WSYNC();
     }
     template <class ST> static __device__ __forceinline__ void push(const ST &S, uint32_t &len, uint2 c, uint32_t lane)
     {
@@ -240,7 +241,7 @@ __device__ __forceinline__ bool vis_test_and_set(uint32_t *tab, uint32_t bmask, 
 struct FusedCtx {
     uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
-    GStore DS; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
+    GStore DS; lds_uint2 *DP; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
     uint32_t tph[13];  // diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
 };
@@ -385,9 +386,38 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         vcount += n_ep;
         for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(p.vis_words >> 2) - 1u, cx.EP[i].y);
     }
+    // Pushes into `discarded` are only read back by a later resume, so they are queued (in the reference's order) and applied
+    // in bulk: a far element -- the usual case -- stops at its parent without moving anything, so a whole run of such pushes is
+    // one gather of the parents and one store of the run; the first element of the queue that does have to climb is pushed the
+    // ordinary way and the rest re-examined.  Same array as pushing one by one.
+    uint32_t ndp = 0;
+    auto d_flush = [&]() {
+        uint32_t done = 0;
+        while (done < ndp && cx.status == FS_OK) {
+            const uint32_t c = ndp - done;
+            if (cx.dlen + c > p.disc_stride + p.disc_lds) { cx.status = FS_OVERFLOW; break; }
+            if (cx.dlen < 64u) { PHeap<true>::push(cx.DS, cx.dlen, make_uint2(cx.DP[done].x, cx.DP[done].y), lane); done++; continue; }   // parents may be queue members
+            PHeap<true>::sync(cx.DS);
+            uint2 it = make_uint2(0u, 0u); bool climbs = false;
+            if (lane < c) {
+                it = make_uint2(cx.DP[done + lane].x, cx.DP[done + lane].y);
+                const uint2 par = cx.DS.ld(((cx.dlen + lane + 1u) >> 1) - 1u);
+                climbs = !PHeap<true>::le(fh_d(it), fh_d(par));
+            }
+            const unsigned long long bad = __ballot(climbs);
+            const uint32_t nb = bad ? (uint32_t)__builtin_ctzll(bad) : c;
+            if (lane < nb) cx.DS.st(cx.dlen + lane, it);
+            cx.dlen += nb; done += nb;
+            if (bad) { PHeap<true>::push(cx.DS, cx.dlen, make_uint2(cx.DP[done].x, cx.DP[done].y), lane); done++; }
+        }
+        PHeap<true>::sync(cx.DS);
+        ndp = 0;
+    };
     auto d_push = [&](uint2 it) {
-        if (cx.dlen >= p.disc_stride + p.disc_lds) { cx.status = FS_OVERFLOW; return; }
-        PHeap<true>::push(cx.DS, cx.dlen, it, lane);
+        if (lane == 0) { cx.DP[ndp].x = it.x; cx.DP[ndp].y = it.y; }
+        ndp++;
+        F_WSYNC();
+        if (ndp == 64u) d_flush();
     };
     // heaps are driven by the whole wave (PHeap) while the candidate heap fits its LDS part; a heap that outgrows it
     // (rare) is handed to the serial hybrid LDS+spill code on lane 0.  clen/wl/rlen: |C|, |W|, result_len -- wave-uniform.
@@ -438,7 +468,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         uint2 popped = make_uint2(0u, 0u); const bool had = clen > 0;
         if (had) popped = c_pop();                                                   // mod.rs:187 (the popped element is the root read above)
         F_TICK(0);
-        if (!go) { if (ITER && had) d_push(popped); break; }                         // scan.rs:341-345
+        if (!go) { if (ITER && had) d_push(popped); break; }                         // scan.rs:341-345 (flushed after the loop)
         if (tm) cx.tph[7]++;
         // a linked element at layer 0 always has level >= 0, so the check of mod.rs:198-200 needs no load there
         if (layer > 0 && clevel < layer) continue;
@@ -497,6 +527,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
                     if (ITER) { d_push(ev); if (cx.status != FS_OK) break; }        // scan.rs:423-428
                 }
             }
+            if (ITER) d_flush();
             __syncthreads();
             F_TICK(6);
             cx.status = __shfl(cx.status, 0, 64);
@@ -505,6 +536,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     }
     if (ITER) {
         while (clen > 0 && cx.status == FS_OK) d_push(c_pop());                      // scan.rs:432-438: what is left of C
+        d_flush();
         cx.vcount = vcount;
     }
     if (lane == 0) cx.CTL[1] = wl;
@@ -546,7 +578,8 @@ k_fused(const FusedParams p_in)
     cx.CTL = cx.IDS + 64;
     p.dsc = (float *)(cx.CTL + 16);
     cx.QV = (uint8_t *)(p.dsc + 64);                      // query parked in LDS (nch KiB)
-    cx.DS.A = (lds_uint2 *)(cx.QV + p.nch * 1024u); cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
+    cx.DP = (lds_uint2 *)(cx.QV + p.nch * 1024u);          // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
+    cx.DS.A = cx.DP + 64; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
     cx.DS.G = MODE == 2 ? p.disc + (size_t)blockIdx.x * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
     cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
@@ -1310,10 +1343,12 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t nch_ = (pitch + 1023) / 1024;
     const uint32_t ccap = FUSED_CCAP;
     uint32_t clds = mode == 1 ? 1024u : 512u;
-    const uint32_t disc_lds = mode == 2 ? 256u : 0u;
+    uint32_t disc_lds = mode == 2 ? 512u : 0u;
+    uint32_t iter_per_cu = 14u;
+    if (mode == 2) { const char *a = getenv("HX_DISC_LDS"), *b = getenv("HX_ITER_PER_CU"); if (a && atoi(a) > 0) disc_lds = (uint32_t)atoi(a); if (b && atoi(b) > 0) iter_per_cu = (uint32_t)atoi(b); }   // tuning knobs
     { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
     clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024 + (size_t)disc_lds * 8; };
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 : 0) * 8; };
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
@@ -1326,8 +1361,8 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         const uint64_t mt = (uint64_t)std::min<long long>(std::max<long long>(it->max_tuples, 1), 1 << 20);
         disc_stride = std::max<uint64_t>(4 * mt, 16384);
         while (vis_words < 8 * mt + 4096) vis_words <<= 1;
-        grid = std::min<uint32_t>(grid, 256u * 8u);
-        const size_t need_disc = (size_t)256 * 8 * disc_stride * 8;
+        grid = std::min<uint32_t>(grid, 256u * iter_per_cu);
+        const size_t need_disc = (size_t)256 * iter_per_cu * disc_stride * 8;
         if (need_disc > mr.cap_disc) {
             if (mr.d_disc) (void)hipFree(mr.d_disc);
             mr.d_disc = nullptr; mr.cap_disc = 0;

@@ -144,6 +144,25 @@ def run(name, n, data="baseline"):
         sub = torch.nonzero(torch.from_numpy(passes).to(DEV)).squeeze(1)
         sc = (bits_pm1(qs[:nqi]) @ rpm[sub].T).float()
         gti = sub[torch.topk(sc, k, dim=1).indices].cpu().numpy()
+        # the oracle (scalar CPU restatement) on the same graph and filter, one host core, 60 queries
+        from oracle import orc
+        lvh = ix.export_levels()
+        o = orc.Index(orc.BIT, orc.HAMMING, dim, m=m, ef_construction=efc, order=orc.SEQ)
+        o.load(rows.cpu().numpy(), lvh, ix.entry, [ix.export_layer(l, with_dist=False) for l in range(int(max(lvh.max(), 0)) + 1)])
+        hq = qs[:60].cpu().numpy()
+        t0 = time.perf_counter()
+        for q in range(len(hq)):
+            import ctypes as C
+            L = orc.lib()
+            qrow = np.ascontiguousarray(hq[q])
+            sc = L.orc_scan_begin(o.h, qrow.ctypes.data_as(C.c_void_p), efs, orc.ITER_RELAXED, iterative["max_scan_tuples"])
+            tid, dd, ee, got = C.c_int64(), C.c_double(), C.c_int(), 0
+            while got < iterative["limit"] and L.orc_scan_next(sc, C.byref(tid), C.byref(dd), C.byref(ee)):   # the executor stops pulling at LIMIT
+                got += int(passes[tid.value])
+            L.orc_scan_end(sc)
+        cpu_it = len(hq) / (time.perf_counter() - t0)
+        del o
+        out["iterative_relaxed_cpu_oracle_1core_qps"] = round(cpu_it, 1)
         out["iterative_relaxed"] = {"queries": nqi, "filter": "tid %% %d == 0" % iterative["filter_every"], "max_scan_tuples": iterative["max_scan_tuples"],
                                     "qps": round(nqi / it_s, 1), "recall_at_10": round(recall(it_tids, it_cnt, gti, k), 4),
                                     "mean_returned": float(it_cnt.mean()), "path": "k_fused MODE 2 (device-resident iterative scan); lock-step host driver when set_fused(False)", "host_profile": it_prof}
