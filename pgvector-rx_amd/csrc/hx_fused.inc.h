@@ -1328,7 +1328,7 @@ static hipError_t launch_fused_mode(hx_engine *e, const FusedParams &p, uint32_t
 // [ntasks][FUSED_MAXL][2m], out_cnt [ntasks][FUSED_MAXL].  status[ntasks].  All host pointers.
 int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                          uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                         uint64_t counts[2], const HxFusedIter *it)
+                         uint64_t counts[2], const HxFusedIter *it, HxFusedView *view)
 {
     HxMirror &mr = mirror;
     if (ntasks == 0) return HX_OK;
@@ -1439,10 +1439,15 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, o - o_st, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
-    memcpy(status, mr.h_io + o_st, (size_t)ntasks * 4);
-    memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
-    memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
-    memcpy(out_d, mr.h_io + o_d, out_n * 4);
+    if (view) {   // the caller reads the pinned staging buffer in place
+        view->status = (const uint32_t *)(mr.h_io + o_st); view->cnt = (const uint32_t *)(mr.h_io + o_cnt);
+        view->ids = (const uint32_t *)(mr.h_io + o_ids); view->d = (const float *)(mr.h_io + o_d);
+    } else {
+        memcpy(status, mr.h_io + o_st, (size_t)ntasks * 4);
+        memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
+        memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
+        memcpy(out_d, mr.h_io + o_d, out_n * 4);
+    }
     if (mode == 2) memcpy(it->out_tix, mr.h_io + o_tix, out_n * 4);
     unsigned long long nd[16]; memcpy(nd, mr.h_io + o_ctr + 8, 128);
     if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))

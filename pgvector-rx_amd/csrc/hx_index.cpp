@@ -757,27 +757,30 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
         int rc = ix->sync_mirror();
         if (rc) return rc;
         const uint32_t n = hi - lo, lm0 = 2u * (uint32_t)g.m;
-        std::vector<uint32_t> qsel(n), status(n), ocnt((size_t)n * HX_FUSED_MAXL), oids((size_t)n * HX_FUSED_MAXL * lm0);
-        std::vector<int32_t> tl(n); std::vector<float> od((size_t)n * HX_FUSED_MAXL * lm0);
+        std::vector<uint32_t> qsel(n); std::vector<int32_t> tl(n);
         for (uint32_t i = 0; i < n; i++) { qsel[i] = bs.base + lo + i; tl[i] = g.level[bs.base + lo + i]; }
         uint64_t cnts[2] = {0, 0};
+        HxFusedView v;                                          // results are read in place from the pinned staging buffer
         auto t0 = std::chrono::steady_clock::now();
         if ((rc = ix->e->fused_run(1, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
-                                   oids.data(), od.data(), ocnt.data(), status.data(), cnts))) return ix->fail(rc, ix->e->err);
+                                   nullptr, nullptr, nullptr, nullptr, cnts, nullptr, &v))) return ix->fail(rc, ix->e->err);
         ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ix->counters[1] += cnts[0]; ix->counters[2] += cnts[1];
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t id = bs.base + lo + i;
-            if (status[i] != 0) { todo.push_back(lo + i); continue; }
-            for (int lc = 0; lc <= g.level[id]; lc++) {
-                const uint32_t c = ocnt[(size_t)i * HX_FUSED_MAXL + lc]; Cand *lst = g.list(id, lc);
-                const size_t ob = ((size_t)i * HX_FUSED_MAXL + lc) * lm0;
-                for (uint32_t k = 0; k < c; k++) lst[k] = Cand{od[ob + k], oids[ob + k]};
-                g.cnt(id, lc) = (uint16_t)c;
+        const uint32_t *status = v.status, *ocnt = v.cnt, *oids = v.ids; const float *od = v.d;
+        ix->pool->parallel_for((n + 511) / 512, [&](size_t ci) {
+            for (uint32_t i = (uint32_t)ci * 512; i < std::min<uint32_t>(n, (uint32_t)ci * 512 + 512); i++) {
+                const uint32_t id = bs.base + lo + i;
+                if (status[i] != 0) continue;
+                for (int lc = 0; lc <= g.level[id]; lc++) {
+                    const uint32_t c = ocnt[(size_t)i * HX_FUSED_MAXL + lc]; Cand *lst = g.list(id, lc);
+                    const size_t ob = ((size_t)i * HX_FUSED_MAXL + lc) * lm0;
+                    for (uint32_t k = 0; k < c; k++) lst[k] = Cand{od[ob + k], oids[ob + k]};
+                    g.cnt(id, lc) = (uint16_t)c;
+                }
+                bs.searched[lo + i] = 1;
             }
-            ix->mark_dirty(id);
-            bs.searched[lo + i] = 1;
-        }
+        });
+        for (uint32_t i = 0; i < n; i++) { if (status[i] != 0) todo.push_back(lo + i); else ix->mark_dirty(bs.base + lo + i); }
         ix->fused_tasks += n; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
     } else {

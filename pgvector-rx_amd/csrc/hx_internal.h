@@ -52,6 +52,9 @@ struct HxMirror {
     uint8_t *h_io = nullptr, *d_io = nullptr; size_t cap_io = 0;
 };
 
+// zero-copy view of a fused_run's results in the engine's pinned staging buffer (valid until the next fused_run)
+struct HxFusedView { const uint32_t *ids = nullptr, *cnt = nullptr, *status = nullptr; const float *d = nullptr; };
+
 // arguments of an iterative scan on the device (k_fused MODE 2)
 struct HxFusedIter {
     int iter_mode = 1; long long max_tuples = 0;       // 1 relaxed_order, 2 strict_order; hnsw.max_scan_tuples
@@ -88,7 +91,7 @@ struct hx_engine {
                   const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs);
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                  uint64_t counts[2], const HxFusedIter *it = nullptr);
+                  uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr);
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 
