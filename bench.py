@@ -131,16 +131,18 @@ def main():
         ix.set_fused(False)
 
     # ---- build (timed once; barrier + sync on both sides; max over ranks) ----
+    # a batch is shared by the ranks, so its cap grows with them: every GPU keeps a full launch of searches per batch
+    eff_batch = min(a.batch * world, 65536)
     dist_stages = None
     barrier()
     t0 = time.perf_counter()
     if world > 1:
         from importlib import import_module
         dbm = import_module("pgvector-rx_amd.dist_build")
-        dbm.insert_sharded(ix, 0, levels, a.batch, dist, xdev)
+        dbm.insert_sharded(ix, 0, levels, eff_batch, dist, xdev)
         dist_stages = {k: round(v, 3) for k, v in dbm.STAGE_SECONDS.items()}
     else:
-        ix.insert(0, levels, batch=a.batch)
+        ix.insert(0, levels, batch=eff_batch)
     barrier()
     build_sec = time.perf_counter() - t0
     if world > 1:
@@ -325,7 +327,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: %d x vector(%d) L2, m=%d ef_construction=%d, build + search on %d MI355X" % (a.rows, a.dim, a.m, a.efc, world),
                    "distribution": a.dist, "ef_search": a.efs, "k": a.k, "queries_per_step": a.queries,
-                   "insert_batch_cap": a.batch, "host_threads": a.threads or min(16, os.cpu_count() or 1)},
+                   "insert_batch_cap": eff_batch, "host_threads": a.threads or min(16, os.cpu_count() or 1)},
         "build_sec": round(build_sec, 2),
         "build_rows_per_s": round(a.rows / build_sec, 1),
         "recall_at_10": round(recall, 4),

@@ -1361,8 +1361,11 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         const uint64_t mt = (uint64_t)std::min<long long>(std::max<long long>(it->max_tuples, 1), 1 << 20);
         disc_stride = std::max<uint64_t>(4 * mt, 16384);
         while (vis_words < 8 * mt + 4096) vis_words <<= 1;
-        grid = std::min<uint32_t>(grid, 256u * iter_per_cu);
-        const size_t need_disc = (size_t)256 * iter_per_cu * disc_stride * 8;
+        // at most ~12 GB of per-query state: a huge max_scan_tuples gets fewer resident queries, never less than one per CU pair
+        const uint64_t per_wg = disc_stride * 8 + vis_words * 4;
+        const uint32_t fit = (uint32_t)std::max<uint64_t>(128, (12ull << 30) / per_wg);
+        grid = std::min<uint32_t>(grid, std::min<uint32_t>(256u * iter_per_cu, fit));
+        const size_t need_disc = (size_t)grid * disc_stride * 8;
         if (need_disc > mr.cap_disc) {
             if (mr.d_disc) (void)hipFree(mr.d_disc);
             mr.d_disc = nullptr; mr.cap_disc = 0;

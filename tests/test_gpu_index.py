@@ -498,7 +498,7 @@ def test_iterative_scan_on_device_equals_lockstep_and_oracle(dt, metric, dim, n,
     nq, efs, limit = 40, 20, 9
     qs = make_rows(dt, nq, dim, rng)
     e.set_queries(qs)
-    for c, max_tuples in [(1, 20000), (40, 20000), (40, 150), (700, 20000), (3, 1)]:
+    for c, max_tuples in [(1, 20000), (40, 20000), (40, 150), (700, 20000), (3, 1), (900, 3_000_000)]:     # the last one sizes the tables for a huge max_scan_tuples
         passes = (np.arange(n) % c == 0).astype(np.uint8)
         before = ix.fused_stats()
         ix.set_fused(True)
