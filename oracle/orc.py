@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_build", "liborc.so")
+LIB_PATH = os.environ.get("ORC_LIB") or os.path.join(HERE, "_build", "liborc.so")   # ORC_LIB: e.g. an ASan/UBSan build of the oracle
 
 F32, F16, BIT = 0, 1, 2
 L2SQ, NEG_IP, L1, HAMMING, JACCARD = 0, 1, 2, 3, 4
