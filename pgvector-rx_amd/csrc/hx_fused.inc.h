@@ -33,6 +33,7 @@ struct FusedParams {
     const uint8_t *rows, *queries; uint32_t pitch, nch; uint64_t n_rows;
     const uint32_t *l0_ids; const uint16_t *l0_cnt; const int32_t *level;
     const uint32_t *up_block, *up_ids; const uint16_t *up_cnt;
+    const float *l0_d, *up_d;                    // stored neighbour distances (the select phase reuses them)
     uint32_t m, entry; int32_t entry_level;
     uint32_t ntasks; const uint32_t *t_qsel; const int32_t *t_level;
     uint32_t ef, k, ccap, clds;                  // ccap: capacity of the candidate heap, its first clds entries in LDS
@@ -243,7 +244,7 @@ struct FusedCtx {
     uint32_t *vis; uint32_t lane; uint32_t status;
     GStore DS; lds_uint2 *DP; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
-    uint32_t tph[13];  // diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
+    uint32_t tph[14];  // [13] select phase; diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
 };
 
 // parks one vector (row or query slot) in LDS, chunk-major: bytes [c*1024 + 16*lane, +16); zero past the pitch
@@ -256,6 +257,20 @@ __device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src,
         *(u4 *)(dst + off) = v;
     }
     __syncthreads();
+}
+
+// f_park without the trip through registers: gfx950's global_load_lds writes each lane's 16 bytes straight to
+// LDS (destination = wave-uniform base + 16 * lane: exactly the parked layout) and completes asynchronously under vmcnt, so the
+// NEXT select candidate's row travels while the current one is being compared.  Lanes past the row's end store zeros themselves.
+__device__ __forceinline__ void f_park_async(const FusedParams &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+{
+    for (uint32_t c = 0; c < p.nch; c++) {
+        const uint32_t off = c * 1024u + lane * 16u;
+        if (off < p.pitch)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(src + off),
+                                             (__attribute__((address_space(3))) uint32_t *)(dst + c * 1024u), 16, 0, 0);
+        else *(u4 *)(dst + off) = u4{0u, 0u, 0u, 0u};
+    }
 }
 
 // Short rows (payload <= 512 B: bit(1024), vector(128), the reference's 3-d tests): a 64-lane wave per row would leave
@@ -588,7 +603,7 @@ k_fused(const FusedParams p_in)
     cx.lane = threadIdx.x;
     cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
     cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
-    for (int i = 0; i < 13; i++) cx.tph[i] = 0;
+    for (int i = 0; i < 14; i++) cx.tph[i] = 0;
     const uint32_t lane = cx.lane;
 
     for (;;) {
@@ -703,26 +718,53 @@ k_fused(const FusedParams p_in)
                 f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
                 n_ep = wl;
                 // select_neighbors(W, lm): mod.rs:269-308
+                const unsigned long long ts0 = (p.fdbg & 4u) ? __builtin_amdgcn_s_memtime() : 0ull;
                 uint32_t r = 0, nd = 0;
                 if (wl <= lm) {
                     for (uint32_t i = lane; i < wl; i += 64) cx.RL[i] = cx.EP[i];
                     r = wl;
                 } else {
+                    // The candidate under test is parked in LDS; the NEXT candidate's row is fetched into the other of two
+                    // buffers (the select scratch in C's LDS part, and the query's slot: d(e, q) is already known, so the query is
+                    // not needed until the next layer's search and is parked again afterwards) while this one is compared.
+                    // Its neighbour list comes along: d(e, r) for an accepted r that is already one of e's neighbours is stored in
+                    // the mirror (the very bits a fresh evaluation gives: every term is symmetric in its operands), so a candidate
+                    // that one of those rules out costs no row traffic at all.
+                    uint8_t *const evb[2] = {cx.EV, cx.QV};
+                    uint32_t nx_id = 0xFFFFFFFFu; float nx_d = 0.0f;                  // lane's slot of the NEXT candidate's list (id, stored distance)
+                    auto list_prefetch = [&](uint32_t el) {
+                        const uint32_t *li; const float *ld; uint32_t lc_n;
+                        if (lc == 0) { li = p.l0_ids + (size_t)el * lm0; ld = p.l0_d + (size_t)el * lm0; lc_n = p.l0_cnt[el]; }
+                        else { const uint32_t blk = p.up_block[el] + (uint32_t)(lc - 1); li = p.up_ids + (size_t)blk * p.m; ld = p.up_d + (size_t)blk * p.m; lc_n = p.up_cnt[blk]; }
+                        nx_id = 0xFFFFFFFFu; nx_d = 0.0f;
+                        if (lane < lc_n) { nx_id = li[lane]; nx_d = ld[lane]; }
+                    };
                     for (uint32_t i = 0; i < wl; i++) {
                         if (r >= lm) break;                                          // mod.rs:285-287
                         const uint2 e = cx.EP[i];
                         bool closer = true;                                          // check_element_closer, mod.rs:315-339
-                        if (r > 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // e's own row and list (requested one iteration ago) have landed
+                        __syncthreads();
+                        const uint32_t my_id = nx_id; const float my_d = nx_d;       // e's list slot of this lane
+                        if (i + 1u < wl) { const uint32_t en = cx.EP[i + 1u].y; f_park_async(p, p.rows + (size_t)en * p.pitch, lane, evb[(i + 1u) & 1u]); list_prefetch(en); }
+                        if (r > 0 && i > 0) {
+                            bool known_hit = false;
+                            if (my_id != 0xFFFFFFFFu && my_d <= fh_d(e)) for (uint32_t j = 0; j < r; j++) known_hit |= cx.RL[j].y == my_id;
+                            if (__ballot(known_hit) != 0ull) closer = false;         // mod.rs:333-335 with a distance we already hold
+                        }
+                        if (r > 0 && closer) {
                             if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
-                            f_park(p, p.rows + (size_t)e.y * p.pitch, lane, cx.EV);
-                            closer = !f_any_le<OP, LPR>(p, cx.EV, cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
+                            __syncthreads();
+                            closer = !f_any_le<OP, LPR>(p, evb[i & 1u], cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
                             __syncthreads();
                         }
                         if (lane == 0) { if (closer) cx.RL[r] = e; else cx.DL[nd] = e; }
                         if (closer) r++; else nd++;
                         __syncthreads();
                     }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no row may still be in flight towards the query's slot
                     __syncthreads();
+                    f_park(p, qsrc, lane, cx.QV);                                    // the query again, for the next layer's search
                     if (lane == 0) for (uint32_t j = 0; j < nd && r < lm; j++) cx.RL[r++] = cx.DL[j];   // mod.rs:300-305
                     r = __shfl(r, 0, 64);
                 }
@@ -731,13 +773,14 @@ k_fused(const FusedParams p_in)
                 for (uint32_t i = lane; i < r; i += 64) { const uint2 v = cx.RL[i]; p.out_ids[lb + i] = v.y; p.out_d[lb + i] = fh_d(v); }
                 if (lane == 0) p.out_cnt[obase + lc] = r;
                 __syncthreads();
+                if (p.fdbg & 4u) cx.tph[13] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts0);
             }
             if (lane == 0) p.status[t] = cx.status;
         }
         __syncthreads();
     }
     if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax);
-                     if (p.fdbg & 4u) { for (int i = 0; i < 13; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
+                     if (p.fdbg & 4u) { for (int i = 0; i < 14; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
 }
 
 // ---- device graph mirror maintenance ------------------------------------------------------------------------
@@ -1418,6 +1461,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     FusedParams p;
     p.rows = d_rows; p.queries = d_queries; p.pitch = (uint32_t)pitch; p.nch = (uint32_t)((pitch + 1023) / 1024); p.n_rows = n_rows;
     p.l0_ids = mr.d_l0_ids; p.l0_cnt = mr.d_l0_cnt; p.level = mr.d_level; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_cnt = mr.d_up_cnt;
+    p.l0_d = mr.d_l0_d; p.up_d = mr.d_up_d;
     p.m = mr.m; p.entry = entry; p.entry_level = entry_level;
     p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(mr.d_io + o_q); p.t_level = (const int32_t *)(mr.d_io + o_lv);
     p.ef = ef; p.k = k; p.ccap = ccap; p.clds = clds;
@@ -1452,10 +1496,10 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         memcpy(out_d, mr.h_io + o_d, out_n * 4);
     }
     if (mode == 2) memcpy(it->out_tix, mr.h_io + o_tix, out_n * 4);
-    unsigned long long nd[16]; memcpy(nd, mr.h_io + o_ctr + 8, 128);
+    unsigned long long nd[17]; memcpy(nd, mr.h_io + o_ctr + 8, 136);
     if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))
-        fprintf(stderr, "[hx] k_fused mode %d tasks %u: 100 MHz ticks summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu\n",
-                mode, ntasks, nd[3], nd[4], nd[5], nd[6], nd[7], nd[8], nd[9], nd[10], nd[11], nd[12], nd[13], nd[14], nd[15]);
+        fprintf(stderr, "[hx] k_fused mode %d tasks %u: 100 MHz ticks summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu; select phase %llu\n",
+                mode, ntasks, nd[3], nd[4], nd[5], nd[6], nd[7], nd[8], nd[9], nd[10], nd[11], nd[12], nd[13], nd[14], nd[15], nd[16]);
     if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }
     if (nd[2] > fused_cmax) fused_cmax = nd[2];
     if (timing) {
