@@ -91,6 +91,8 @@ def lib():
         "hx_index_load_pages": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
+        if os.environ.get("HX_LIB") and not hasattr(L, name):
+            continue                # an older variant library loaded for an A/B timing run (tools/qsweep.py) may lack newer entry points
         fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
         fn.restype, fn.argtypes = res, args
     _lib = L

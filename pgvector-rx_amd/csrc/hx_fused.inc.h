@@ -1484,7 +1484,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));
-    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, o - o_st, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, (mode == 2 ? o : o_tix) - o_st, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
     if (view) {   // the caller reads the pinned staging buffer in place
         view->status = (const uint32_t *)(mr.h_io + o_st); view->cnt = (const uint32_t *)(mr.h_io + o_cnt);

@@ -1190,29 +1190,33 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
         if (rc) return rc;
         const Graph &g = ix->g;
         const uint32_t ke = std::min<uint32_t>(limit, ef_search);
-        std::vector<uint32_t> qsel(nq), status(nq), ocnt(nq), oids((size_t)nq * ke);
-        std::vector<float> od((size_t)nq * ke);
+        std::vector<uint32_t> qsel(nq);
         for (uint32_t q = 0; q < nq; q++) qsel[q] = HX_QUERY_SLOT | q;
         uint64_t cnts[2] = {0, 0};
+        HxFusedView v;                                          // results are read in place from the pinned staging buffer
         auto t0 = std::chrono::steady_clock::now();
         if ((rc = ix->e->fused_run(0, nq, qsel.data(), nullptr, ef_search, ke, (uint32_t)g.entry, g.level[g.entry],
-                                   oids.data(), od.data(), ocnt.data(), status.data(), cnts))) return ix->fail(rc, ix->e->err);
+                                   nullptr, nullptr, nullptr, nullptr, cnts, nullptr, &v))) return ix->fail(rc, ix->e->err);
         ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ix->counters[4] += cnts[0];
-        for (uint32_t q = 0; q < nq; q++) {
-            if (status[q] != 0) { todo.push_back(q); continue; }
-            uint32_t c = 0;                                      // amgettuple: every heap TID of each element, nearest first (scan.rs:794-875)
-            for (uint32_t i = 0; i < ocnt[q] && c < limit; i++) {
-                const uint32_t el = oids[(size_t)q * ke + i];
-                for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
-                    tids_out[(size_t)q * limit + c] = g.tids[el][t];
-                    if (dist_out) dist_out[(size_t)q * limit + c] = od[(size_t)q * ke + i];
-                    if (elems_out) elems_out[(size_t)q * limit + c] = el;
-                    c++;
+        const uint32_t *status = v.status, *ocnt = v.cnt, *oids = v.ids; const float *od = v.d;
+        ix->pool->parallel_for((nq + 1023) / 1024, [&](size_t ci) {
+            for (uint32_t q = (uint32_t)ci * 1024; q < std::min<uint32_t>(nq, (uint32_t)ci * 1024 + 1024); q++) {
+                if (status[q] != 0) continue;
+                uint32_t c = 0;                                  // amgettuple: every heap TID of each element, nearest first (scan.rs:794-875)
+                for (uint32_t i = 0; i < ocnt[q] && c < limit; i++) {
+                    const uint32_t el = oids[(size_t)q * ke + i];
+                    for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
+                        tids_out[(size_t)q * limit + c] = g.tids[el][t];
+                        if (dist_out) dist_out[(size_t)q * limit + c] = od[(size_t)q * ke + i];
+                        if (elems_out) elems_out[(size_t)q * limit + c] = el;
+                        c++;
+                    }
                 }
+                counts_out[q] = c;
             }
-            counts_out[q] = c;
-        }
+        });
+        for (uint32_t q = 0; q < nq; q++) if (status[q] != 0) todo.push_back(q);
         ix->fused_tasks += nq; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
     } else if (mode != 0 && ix->fused_ok() && ix->g.entry >= 0 && limit <= 4096) {
