@@ -24,6 +24,9 @@
 #ifndef FUSED_MINW
 #define FUSED_MINW 4
 #endif
+#ifndef FUSED_MINW_ITER
+#define FUSED_MINW_ITER 3          /* the iterative-scan kernel carries more state: 168 VGPRs instead of spilling 230 */
+#endif
 #define FUSED_CG 3             /* ... times chunks of each requested at once */
 #define FUSED_CCAP 8192u       /* candidate-heap capacity per search (LDS head + global spill) */
 #define FUSED_MAXL 8           /* layers 0..7 handled on the device (P(level >= 8) = 16^-8 at m=16) */
@@ -575,7 +578,7 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
 }
 
 template <class OP, int MODE, int LPR>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors); LPR: lanes per row (64, or 8/32 for short rows)
-__global__ void __launch_bounds__(64, FUSED_MINW)
+__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : FUSED_MINW))
 k_fused(const FusedParams p_in)
 {
     FusedParams p = p_in;
