@@ -245,7 +245,7 @@ __device__ __forceinline__ bool vis_test_and_set(uint32_t *tab, uint32_t bmask, 
 struct FusedCtx {
     uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
-    GStore DS; lds_uint2 *DP; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
+    GStore DS; lds_uint2 *DP, *WS; uint32_t *LV; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
     uint32_t tph[14];  // [13] select phase; diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
 };
@@ -405,31 +405,84 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(p.vis_words >> 2) - 1u, cx.EP[i].y);
     }
     // Pushes into `discarded` are only read back by a later resume, so they are queued (in the reference's order) and applied
-    // in bulk: a far element -- the usual case -- stops at its parent without moving anything, so a whole run of such pushes is
-    // one gather of the parents and one store of the run; the first element of the queue that does have to climb is pushed the
-    // ordinary way and the rest re-examined.  Same array as pushing one by one.
+    // per expansion.  The new slots are consecutive, so at every level their ancestors form ONE contiguous index range: those
+    // ranges (< 2c + depth entries for c queued pushes) are gathered into an LDS working set with one round of loads, the c
+    // sift-ups run on the working set in queue order -- LDS latency instead of a memory hop each -- and the ranges are stored
+    // back.  Same array as pushing one by one into the heap itself.
     uint32_t ndp = 0;
-    auto d_flush = [&]() {
-        uint32_t done = 0;
-        while (done < ndp && cx.status == FS_OK) {
-            const uint32_t c = ndp - done;
-            if (cx.dlen + c > p.disc_stride + p.disc_lds) { cx.status = FS_OVERFLOW; break; }
-            if (cx.dlen < 64u) { PHeap<true>::push(cx.DS, cx.dlen, make_uint2(cx.DP[done].x, cx.DP[done].y), lane); done++; continue; }   // parents may be queue members
-            PHeap<true>::sync(cx.DS);
-            uint2 it = make_uint2(0u, 0u); bool climbs = false;
-            if (lane < c) {
-                it = make_uint2(cx.DP[done + lane].x, cx.DP[done + lane].y);
-                const uint2 par = cx.DS.ld(((cx.dlen + lane + 1u) >> 1) - 1u);
-                climbs = !PHeap<true>::le(fh_d(it), fh_d(par));
-            }
-            const unsigned long long bad = __ballot(climbs);
-            const uint32_t nb = bad ? (uint32_t)__builtin_ctzll(bad) : c;
-            if (lane < nb) cx.DS.st(cx.dlen + lane, it);
-            cx.dlen += nb; done += nb;
-            if (bad) { PHeap<true>::push(cx.DS, cx.dlen, make_uint2(cx.DP[done].x, cx.DP[done].y), lane); done++; }
+    // queue members [j0, j0 + c) -> heap slots [dlen, dlen + c); all of them lie on the same tree level (the caller splits a
+    // queue that crosses a power of two), so "k levels up" is the same tree depth for every member and the level ranges are disjoint
+    auto d_flush_range = [&](const uint32_t j0, const uint32_t c) {
+        const uint32_t p0 = cx.dlen;
+        const uint32_t depth = 31u - (uint32_t)__builtin_clz(p0 + c);       // levels 1..depth above the new slots (1-based heap indices)
+        auto lo_of = [&](uint32_t k) { const uint32_t v = (p0 + 1u) >> k; return v ? v : 1u; };
+        auto hi_of = [&](uint32_t k) { return (p0 + c) >> k; };
+        if (lane >= 1u && lane <= depth) {                                 // per level: first index, offset of its range in the working set
+            uint32_t base = 0;
+            for (uint32_t k = 1; k < lane; k++) base += hi_of(k) - lo_of(k) + 1u;
+            cx.LV[2u * lane] = lo_of(lane); cx.LV[2u * lane + 1u] = base;
         }
+        uint32_t total = 0;
+        for (uint32_t k = 1; k <= depth; k++) total += hi_of(k) - lo_of(k) + 1u;
+        F_WSYNC();
+        // gather: working-set slot f <-> (level, index)
+        uint32_t my_idx[2] = {0u, 0u};
+        for (int h = 0; h < 2; h++) {
+            const uint32_t f = lane + 64u * (uint32_t)h;
+            if (f < total) {
+                uint32_t k = 1, base = 0;
+                for (;; k++) { const uint32_t len = hi_of(k) - lo_of(k) + 1u; if (f < base + len) break; base += len; }
+                my_idx[h] = lo_of(k) + (f - base);
+                const uint2 v = cx.DS.ld(my_idx[h] - 1u);
+                cx.WS[f].x = v.x; cx.WS[f].y = v.y;
+            }
+        }
+        F_WSYNC();
+        for (uint32_t j = 0; j < c; j++) {                                 // the c sift-ups, in queue order, on the working set
+            const uint32_t pos1 = p0 + 1u + j;
+            const uint2 it = make_uint2(cx.DP[j0 + j].x, cx.DP[j0 + j].y);
+            const uint32_t dj = 31u - (uint32_t)__builtin_clz(pos1);
+            const bool anc = lane >= 1u && lane <= dj;
+            uint2 v = make_uint2(0u, 0u);
+            if (anc) { const uint32_t s0 = cx.LV[2u * lane + 1u] + ((pos1 >> lane) - cx.LV[2u * lane]); v = make_uint2(cx.WS[s0].x, cx.WS[s0].y); }
+            const unsigned long long sm = __ballot(anc && PHeap<true>::le(fh_d(it), fh_d(v)));
+            const uint32_t t = sm ? (uint32_t)__builtin_ctzll(sm) : dj + 1u;
+            F_WSYNC();
+            if (anc && lane < t) {                                         // ancestor `lane` moves down to the path's slot one level below
+                if (lane == 1u) { cx.DP[j0 + j].x = v.x; cx.DP[j0 + j].y = v.y; }
+                else { const uint32_t s1 = cx.LV[2u * (lane - 1u) + 1u] + ((pos1 >> (lane - 1u)) - cx.LV[2u * (lane - 1u)]); cx.WS[s1].x = v.x; cx.WS[s1].y = v.y; }
+            }
+            if (lane == 0u && t > 1u) {                                    // the new element lands at level t-1 (t == 1: it stays in its own slot, DP[j])
+                const uint32_t s1 = cx.LV[2u * (t - 1u) + 1u] + ((pos1 >> (t - 1u)) - cx.LV[2u * (t - 1u)]);
+                cx.WS[s1].x = it.x; cx.WS[s1].y = it.y;
+            }
+            F_WSYNC();
+        }
+        // store back: the ranges, then the new slots
+        for (int h = 0; h < 2; h++) {
+            const uint32_t f = lane + 64u * (uint32_t)h;
+            if (f < total) cx.DS.st(my_idx[h] - 1u, make_uint2(cx.WS[f].x, cx.WS[f].y));
+        }
+        if (lane < c) cx.DS.st(p0 + lane, make_uint2(cx.DP[j0 + lane].x, cx.DP[j0 + lane].y));
+        cx.dlen = p0 + c;
         PHeap<true>::sync(cx.DS);
+    };
+    auto d_flush = [&]() {
+        const uint32_t c = ndp;
         ndp = 0;
+        if (c == 0 || cx.status != FS_OK) return;
+        if (cx.dlen + c > p.disc_stride + p.disc_lds) { cx.status = FS_OVERFLOW; return; }
+        uint32_t j0 = 0;
+        while (j0 < c) {
+            if (cx.dlen < 64u) {                                           // small heap: ancestors may be queue members themselves
+                PHeap<true>::push(cx.DS, cx.dlen, make_uint2(cx.DP[j0].x, cx.DP[j0].y), lane); j0++; continue;
+            }
+            const uint32_t first1 = cx.dlen + 1u;                          // 1-based slot of the next member
+            const uint32_t level_end = (2u << (31u - (uint32_t)__builtin_clz(first1))) - 1u;   // last slot of its tree level
+            const uint32_t cs = (c - j0) < (level_end - first1 + 1u) ? (c - j0) : (level_end - first1 + 1u);
+            d_flush_range(j0, cs);
+            j0 += cs;
+        }
     };
     auto d_push = [&](uint2 it) {
         if (lane == 0) { cx.DP[ndp].x = it.x; cx.DP[ndp].y = it.y; }
@@ -597,7 +650,8 @@ k_fused(const FusedParams p_in)
     p.dsc = (float *)(cx.CTL + 16);
     cx.QV = (uint8_t *)(p.dsc + 64);                      // query parked in LDS (nch KiB)
     cx.DP = (lds_uint2 *)(cx.QV + p.nch * 1024u);          // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
-    cx.DS.A = cx.DP + 64; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
+    cx.WS = cx.DP + 64; cx.LV = (uint32_t *)(cx.WS + 160);   // working set of a flush (<= 2*64 + depth entries), per-level {first index, offset}
+    cx.DS.A = cx.WS + 160 + 32; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
     cx.DS.G = MODE == 2 ? p.disc + (size_t)blockIdx.x * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
     cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
@@ -1394,7 +1448,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     if (mode == 2) { const char *a = getenv("HX_DISC_LDS"), *b = getenv("HX_ITER_PER_CU"); if (a && atoi(a) > 0) disc_lds = (uint32_t)atoi(a); if (b && atoi(b) > 0) iter_per_cu = (uint32_t)atoi(b); }   // tuning knobs
     { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
     clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 : 0) * 8; };
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
