@@ -1307,7 +1307,8 @@ static hipError_t launch_links(hx_engine *e, const LinksParams &p)
 }
 
 int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
-                         const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs)
+                         const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs,
+                         bool want_lists)
 {
     HxMirror &mr = mirror;
     if (n_groups == 0) return HX_OK;
@@ -1383,12 +1384,31 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
     HX_HIP(this, hipMemcpyAsync(h + o_ctr, mr.d_lk + o_ctr, 64, hipMemcpyDeviceToHost, stream));
-    HX_HIP(this, hipMemcpyAsync(h + o_cnt, mr.d_lk + o_cnt, o - o_cnt, hipMemcpyDeviceToHost, stream));
+    if (want_lists) HX_HIP(this, hipMemcpyAsync(h + o_cnt, mr.d_lk + o_cnt, o - o_cnt, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
     *out_cnt = (const uint32_t *)(h + o_cnt); *out_ids = (const uint32_t *)(h + o_ids); *out_d = (const float *)(h + o_d);
     unsigned long long np; memcpy(&np, h + o_ctr, 8);
     if (n_pairs) *n_pairs = np;
     if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    return HX_OK;
+}
+
+int hx_engine::mirror_download(uint64_t n_elems, uint64_t n_blocks, uint32_t *l0_ids, float *l0_d, uint16_t *l0_cnt, uint32_t *up_ids, float *up_d, uint16_t *up_cnt)
+{
+    HxMirror &mr = mirror;
+    HX_HIP(this, hipSetDevice(device));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    const size_t lm0 = 2u * (size_t)mr.m;
+    if (n_elems) {
+        HX_HIP(this, hipMemcpy(l0_ids, mr.d_l0_ids, n_elems * lm0 * 4, hipMemcpyDeviceToHost));
+        HX_HIP(this, hipMemcpy(l0_d, mr.d_l0_d, n_elems * lm0 * 4, hipMemcpyDeviceToHost));
+        HX_HIP(this, hipMemcpy(l0_cnt, mr.d_l0_cnt, n_elems * 2, hipMemcpyDeviceToHost));
+    }
+    if (n_blocks) {
+        HX_HIP(this, hipMemcpy(up_ids, mr.d_up_ids, n_blocks * mr.m * 4, hipMemcpyDeviceToHost));
+        HX_HIP(this, hipMemcpy(up_d, mr.d_up_d, n_blocks * mr.m * 4, hipMemcpyDeviceToHost));
+        HX_HIP(this, hipMemcpy(up_cnt, mr.d_up_cnt, n_blocks * 2, hipMemcpyDeviceToHost));
+    }
     return HX_OK;
 }
 

@@ -135,6 +135,12 @@ struct Graph {
     int64_t entry = -1;
 
     uint32_t size() const { return (uint32_t)level.size(); }
+    void reserve(size_t n)      // no reallocation (and re-copy of gigabytes) while a bulk insert appends n more elements
+    {
+        const size_t t = level.size() + n;
+        level.reserve(t); n0_cnt.reserve(t); n0.reserve(t * 2 * (size_t)m); up_off.reserve(t); upc_off.reserve(t); tids.reserve(t); ntids.reserve(t);
+        up.reserve(up.size() + n / 8 * (size_t)m + 64); up_cnt.reserve(up_cnt.size() + n / 8 + 64);
+    }
     int lm(int layer) const { return layer == 0 ? 2 * m : m; }       // hnsw_get_layer_m, hnsw_constants.rs:122-128
     uint32_t add(int lv)
     {
@@ -543,6 +549,7 @@ struct Pool {
 // ================================================================================================
 struct BatchState {
     bool open = false, linked = false;
+    bool lazy_lists = false;     // single-process insert: lists pruned on the device are not copied back per batch (hx_index::ensure_host_lists)
     uint32_t base = 0, b = 0, entry = 0; int entry_level = 0;
     std::vector<int64_t> tids; std::vector<uint32_t> elem; std::vector<uint8_t> searched;
     std::vector<BackOp> ops; std::vector<std::pair<size_t, size_t>> grp;
@@ -601,9 +608,31 @@ struct hx_index {
     // and ONE pair launch.  At most `window` tasks are live at a time; finished ones are replaced from the rest of
     // `tasks` (continuous admission keeps the launches full until the tail).
     struct ChunkSum { size_t alive = 0, dgroups = 0, dids = 0, pgroups = 0, pids = 0, pout = 0; };
+    // Lists pruned by k_links live in the device mirror first; the host copy is refreshed in one sweep when something on
+    // the host needs to read lists (lock-step tasks, export, serialisation).  sync_mirror() goes first so that lists the
+    // host wrote since the last launch are in the mirror too, which makes the sweep a plain overwrite.
+    bool host_stale = false, in_insert = false;
+    int ensure_host_lists()
+    {
+        if (!host_stale) return HX_OK;
+        int rc = sync_mirror();
+        if (rc) return rc;
+        const uint32_t n = mirror_elems, m = (uint32_t)g.m; const size_t lm0 = 2u * (size_t)m, nb = g.up_cnt.size();
+        std::vector<uint32_t> ids((size_t)n * lm0), uids(nb * m); std::vector<float> dd((size_t)n * lm0), ud(nb * m);
+        std::vector<uint16_t> ucnt(nb);
+        if ((rc = e->mirror_download(n, nb, ids.data(), dd.data(), g.n0_cnt.data(), uids.data(), ud.data(), ucnt.data()))) return fail(rc, e->err);
+        pool->parallel_for((n + 8191) / 8192, [&](size_t ci) {
+            for (size_t el = ci * 8192; el < std::min<size_t>(n, ci * 8192 + 8192); el++)
+                for (size_t k = 0; k < lm0; k++) g.n0[el * lm0 + k] = Cand{dd[el * lm0 + k], ids[el * lm0 + k]};
+        });
+        for (size_t b = 0; b < nb; b++) { g.up_cnt[b] = ucnt[b]; for (uint32_t k = 0; k < m; k++) g.up[b * m + k] = Cand{ud[b * m + k], uids[b * m + k]}; }
+        host_stale = false;
+        return HX_OK;
+    }
     int run_lockstep(std::vector<LsTask *> &tasks, size_t window = 0)
     {
         if (tasks.empty()) return HX_OK;
+        { int rc0 = ensure_host_lists(); if (rc0) return rc0; }
         if (window == 0 || window > tasks.size()) window = tasks.size();
         std::vector<LsTask *> live(tasks.begin(), tasks.begin() + window), live2;
         size_t admitted = window;
@@ -738,6 +767,7 @@ int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int
     if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
     if (first_row + b > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
     const int mxl = max_level_for(g.m);
+    if (!ix->in_insert) { int rc0 = ix->ensure_host_lists(); if (rc0) return rc0; }   // an external (multi-GPU) driver exports lists from the host copy
     bs = BatchState();
     bs.open = true; bs.base = g.size(); bs.b = b; bs.entry = (uint32_t)g.entry; bs.entry_level = g.level[g.entry];
     bs.tids.assign(tids, tids + b); bs.elem.assign(b, 0); bs.searched.assign(b, 0);
@@ -965,8 +995,11 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
             hx_index::Timer tl(ix->prof[9]);
             const uint32_t *oids = nullptr, *ocnt = nullptr; const float *odd = nullptr;
             uint64_t np = 0;
-            if ((rc = ix->e->links_run(ng, tg.data(), ly.data(), off.data(), onew.data(), od.data(), &oids, &odd, &ocnt, &np))) return ix->fail(rc, ix->e->err);
+            const bool lazy = bs.lazy_lists;
+            if ((rc = ix->e->links_run(ng, tg.data(), ly.data(), off.data(), onew.data(), od.data(), &oids, &odd, &ocnt, &np, !lazy))) return ix->fail(rc, ix->e->err);
             ix->counters[3] += np;
+            if (lazy) ix->host_stale = true;
+            else
             ix->pool->parallel_for((ng + 2047) / 2048, [&](size_t ci) {
                 for (size_t gi = ci * 2048; gi < std::min<size_t>(ng, ci * 2048 + 2048); gi++) {
                     Cand *lst = g.list(tg[gi], (int)ly[gi]); const uint32_t c = ocnt[gi];
@@ -1070,6 +1103,7 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
     if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
     if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
     if (batch == 0) batch = 1;
+    g.reserve(n);
     const int mxl = max_level_for(g.m);
     uint32_t done = 0;
     while (done < n) {
@@ -1088,7 +1122,11 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
             if (b == 0) continue;
         }
         int rc;
-        if ((rc = hx_index_batch_begin(ix, first_row + done, b, levels + done, tids + done))) return rc;
+        ix->in_insert = true;
+        rc = hx_index_batch_begin(ix, first_row + done, b, levels + done, tids + done);
+        ix->in_insert = false;
+        if (rc) return rc;
+        ix->bs.lazy_lists = true;
         if ((rc = hx_index_batch_search(ix, 0, b)) || (rc = hx_index_batch_links(ix, 0, 1)) ||
             (rc = hx_index_batch_end(ix, elem_out ? elem_out + done : nullptr))) { ix->bs = BatchState(); return rc; }
         done += b;
@@ -1102,6 +1140,7 @@ int hx_index_level(const hx_index *ix, uint32_t elem) { if (!ix || elem >= ix->g
 
 int hx_index_neighbors(const hx_index *ix, uint32_t elem, int layer, uint32_t *ids_out, float *dist_out)
 {
+    if (ix && const_cast<hx_index *>(ix)->ensure_host_lists()) return HX_E_HIP - 1000;
     if (!ix || elem >= ix->g.size()) return HX_E_ARG;
     const Graph &g = ix->g;
     const int lv = g.level[elem] < 0 ? -1 - g.level[elem] : g.level[elem];
@@ -1128,6 +1167,7 @@ int hx_index_export_levels(const hx_index *ix, uint32_t first, uint32_t n, int32
 
 int hx_index_export_layer(const hx_index *ix, int layer, uint32_t first, uint32_t n, uint32_t *ids_out, float *dist_out, uint16_t *cnt_out)
 {
+    if (ix) { int rc0 = const_cast<hx_index *>(ix)->ensure_host_lists(); if (rc0) return rc0; }
     if (!ix || layer < 0 || (n && (!ids_out || !cnt_out)) || (uint64_t)first + n > ix->g.size()) return HX_E_ARG;
     const Graph &g = ix->g; const size_t lm = (size_t)g.lm(layer);
     for (uint32_t i = 0; i < n; i++) {
@@ -1142,6 +1182,7 @@ int hx_index_export_layer(const hx_index *ix, int layer, uint32_t first, uint32_
 
 int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t count, const uint32_t *ids, const float *dist)
 {
+    if (ix) { int rc0 = ix->ensure_host_lists(); if (rc0) return rc0; }
     if (!ix || elem >= ix->g.size()) return HX_E_ARG;
     Graph &g = ix->g;
     if (layer < 0 || g.level[elem] < layer || count > (uint32_t)g.lm(layer) || (count && (!ids || !dist))) return ix->fail(HX_E_ARG, "bad neighbour list");
@@ -1356,6 +1397,7 @@ int hx_index_serialize_pages(const hx_index *cix, uint8_t *pages_out, uint64_t c
 {
     if (!cix || !n_pages_out) return HX_E_ARG;
     hx_index *ix = const_cast<hx_index *>(cix);
+    { int rc0 = ix->ensure_host_lists(); if (rc0) return rc0; }
     const Graph &g = ix->g;
     const hx_engine *e = ix->e;
     const uint32_t n = g.size(), m = (uint32_t)g.m;

@@ -87,8 +87,11 @@ struct hx_engine {
     // update_neighbor_connections on the device for n_groups (target, layer) lists: group g applies ops
     // [op_off[g], op_off[g+1]) = (new element, its distance to the target) in order; the lists are read from and written
     // back to the mirror, and returned: out_cnt[g], out_ids/out_d [g][2m]
+    // copies the mirror's lists of elements [0, n_elems) / upper-layer blocks [0, n_blocks) to host arrays (ids and distances SoA, counts)
+    int mirror_download(uint64_t n_elems, uint64_t n_blocks, uint32_t *l0_ids, float *l0_d, uint16_t *l0_cnt, uint32_t *up_ids, float *up_d, uint16_t *up_cnt);
     int links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
-                  const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs);
+                  const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs,
+                  bool want_lists = true);   // false: the updated lists stay in the mirror only (the host pulls them when it needs them)
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
                   uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr);
