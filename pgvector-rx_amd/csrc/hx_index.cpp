@@ -612,6 +612,9 @@ struct hx_index {
     // the host needs to read lists (lock-step tasks, export, serialisation).  sync_mirror() goes first so that lists the
     // host wrote since the last launch are in the mirror too, which makes the sweep a plain overwrite.
     bool host_stale = false, in_insert = false;
+    // scratch of hx_index_batch_links, kept between batches (a batch allocates and page-faults ~10 MB otherwise)
+    struct LinkScratch { std::vector<BackOp> raw; std::vector<uint32_t> hist, own, tg, ly, off, onew, opstart, da, db, dstart; std::vector<float> od; std::vector<uint8_t> deq;
+                         std::vector<std::vector<std::pair<size_t, size_t>>> bgrp; } ls;
     int ensure_host_lists()
     {
         if (!host_stale) return HX_OK;
@@ -768,7 +771,12 @@ int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int
     if (first_row + b > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
     const int mxl = max_level_for(g.m);
     if (!ix->in_insert) { int rc0 = ix->ensure_host_lists(); if (rc0) return rc0; }   // an external (multi-GPU) driver exports lists from the host copy
-    bs = BatchState();
+    {   // keep the vectors' capacity from batch to batch
+        BatchState fresh;
+        fresh.tids.swap(bs.tids); fresh.elem.swap(bs.elem); fresh.searched.swap(bs.searched); fresh.ops.swap(bs.ops); fresh.grp.swap(bs.grp);
+        fresh.tids.clear(); fresh.elem.clear(); fresh.searched.clear(); fresh.ops.clear(); fresh.grp.clear();
+        bs = std::move(fresh);
+    }
     bs.open = true; bs.base = g.size(); bs.b = b; bs.entry = (uint32_t)g.entry; bs.entry_level = g.level[g.entry];
     bs.tids.assign(tids, tids + b); bs.elem.assign(b, 0); bs.searched.assign(b, 0);
     for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[i], mxl); if (lv < 0) lv = 0; g.add(lv); }
@@ -895,16 +903,16 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
     int rc;
     double t_links0 = hx_index::now_s();
     // duplicate detection (build.rs:482-512): byte-compare the leading zero-distance layer-0 neighbours
-    std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0);
+    auto &da = ix->ls.da; auto &db = ix->ls.db; auto &dstart = ix->ls.dstart; da.clear(); db.clear(); dstart.assign(b + 1, 0u);
     for (uint32_t i = 0; i < b; i++) {
         const uint32_t id = base + i; const Cand *l0 = g.list(id, 0);
         for (uint16_t k = 0; k < g.cnt(id, 0); k++) { if (l0[k].d != 0.0f) break; da.push_back(id); db.push_back(l0[k].id); }
         dstart[i + 1] = (uint32_t)da.size();
     }
-    std::vector<uint8_t> deq(da.size());
+    auto &deq = ix->ls.deq; deq.assign(da.size(), 0);
     if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
     std::vector<BackOp> &ops = bs.ops; ops.clear();
-    std::vector<uint32_t> opstart(b + 1, 0);                    // ops of member i land at [opstart[i], opstart[i+1])
+    auto &opstart = ix->ls.opstart; opstart.assign(b + 1, 0u);   // ops of member i land at [opstart[i], opstart[i+1])
     for (uint32_t i = 0; i < b; i++) {
         const uint32_t id = base + i;
         int64_t dup = -1;
@@ -930,8 +938,8 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         const uint32_t n_ops = opstart[b];
         constexpr uint32_t NB = 256;
         const uint32_t csz = 128, nck = (b + csz - 1) / csz;
-        std::vector<BackOp> raw(n_ops);
-        std::vector<uint32_t> hist((size_t)nck * NB, 0u);
+        auto &raw = ix->ls.raw; raw.resize(n_ops);
+        auto &hist = ix->ls.hist; hist.assign((size_t)nck * NB, 0u);
         ix->pool->parallel_for(nck, [&](size_t ci) {
             uint32_t *h = &hist[ci * NB];
             for (uint32_t i = (uint32_t)ci * csz; i < std::min(b, (uint32_t)(ci + 1) * csz); i++) {
@@ -957,7 +965,7 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
             const uint32_t lo = opstart[std::min<size_t>(b, ci * csz)], hi = opstart[std::min<size_t>(b, (ci + 1) * csz)];
             for (uint32_t o = lo; o < hi; o++) if (raw[o].layer >= 0) ops[cur[raw[o].target & (NB - 1)]++] = raw[o];
         });
-        std::vector<std::vector<std::pair<size_t, size_t>>> bgrp(NB);
+        auto &bgrp = ix->ls.bgrp; bgrp.resize(NB); for (auto &v : bgrp) v.clear();
         ix->pool->parallel_for(NB, [&](size_t bk) {
             std::stable_sort(ops.begin() + bstart[bk], ops.begin() + bstart[bk + 1],
                              [](const BackOp &a, const BackOp &c) { return a.target != c.target ? a.target < c.target : a.layer < c.layer; });
@@ -973,15 +981,15 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
     if (ix->fused_ok() && g.lm(0) + 1 <= 33) {
         // device path: k_links applies every owned list's back-links (append / prune) in one launch
         if ((rc = ix->sync_mirror())) return rc;
-        std::vector<uint32_t> own;                               // indices into bs.grp of the lists this rank owns
+        auto &own = ix->ls.own; own.clear();                     // indices into bs.grp of the lists this rank owns
         own.reserve(bs.grp.size());
         for (uint32_t gi = 0; gi < bs.grp.size(); gi++) if (ops[bs.grp[gi].first].target % world == rank) own.push_back(gi);
         const uint32_t ng = (uint32_t)own.size(), lm0 = 2u * (uint32_t)g.m;
-        std::vector<uint32_t> tg(ng), ly(ng), off(ng + 1, 0u);
+        auto &tg = ix->ls.tg; auto &ly = ix->ls.ly; auto &off = ix->ls.off; tg.resize(ng); ly.resize(ng); off.assign(ng + 1, 0u);
         for (uint32_t k = 0; k < ng; k++) off[k + 1] = off[k] + (uint32_t)(bs.grp[own[k]].second - bs.grp[own[k]].first);
         for (uint32_t k = 0; k < ng; k++) ix->prof[13] = std::max(ix->prof[13], (double)(off[k + 1] - off[k]));   // longest serial op chain of one list
         ix->prof[14] += off[ng];
-        std::vector<uint32_t> onew(off[ng]); std::vector<float> od(off[ng]);
+        auto &onew = ix->ls.onew; auto &od = ix->ls.od; onew.resize(off[ng]); od.resize(off[ng]);
         ix->pool->parallel_for((ng + 4095) / 4096, [&](size_t ci) {
             for (size_t k = ci * 4096; k < std::min<size_t>(ng, ci * 4096 + 4096); k++) {
                 const auto &gr = bs.grp[own[k]];
@@ -1087,7 +1095,7 @@ int hx_index_batch_end(hx_index *ix, uint32_t *elem_out)
     BatchState &bs = ix->bs;
     if (!bs.open || !bs.linked) return ix->fail(HX_E_STATE, "batch not linked yet");
     if (elem_out) memcpy(elem_out, bs.elem.data(), (size_t)bs.b * sizeof(uint32_t));
-    bs = BatchState();
+    bs.open = false; bs.linked = false; bs.lazy_lists = false; bs.b = 0;      // vectors keep their capacity for the next batch
     return HX_OK;
 }
 
