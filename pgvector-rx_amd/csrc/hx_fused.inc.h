@@ -262,6 +262,18 @@ __device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src,
     __syncthreads();
 }
 
+// f_park for code that runs in ONE wave of a multi-wave workgroup (no workgroup barrier)
+__device__ __forceinline__ void f_park_w(const FusedParams &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+{
+    for (uint32_t c = 0; c < p.nch; c++) {
+        const uint32_t off = c * 1024u + lane * 16u;
+        u4 v = {0u, 0u, 0u, 0u};
+        if (off < p.pitch) v = *(const u4 *)(src + off);
+        *(u4 *)(dst + off) = v;
+    }
+    F_WSYNC();
+}
+
 // f_park without the trip through registers: gfx950's global_load_lds writes each lane's 16 bytes straight to
 // LDS (destination = wave-uniform base + 16 * lane: exactly the parked layout) and completes asynchronously under vmcnt, so the
 // NEXT select candidate's row travels while the current one is being compared.  Lanes past the row's end store zeros themselves.
@@ -1119,6 +1131,130 @@ k_links(const LinksParams p)
 #define LC_TRI (LC_SLOTS * (LC_SLOTS - 1) / 2)     /* 496 */
 __device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > j ? i * (i - 1) / 2 + j : j * (j - 1) / 2 + i; }
 
+// One back-link op (new_id at distance new_d) on the list held in LDS: update_neighbor_connections' body, mod.rs:458-487.
+// Runs in ONE wave (wave-level ordering only), on the list state (M, lid, ld, cnt, v) and the scratch arrays it is given.
+// SPEC == false: applies the op; returns true when the list was pruned (it is then in select order, its matrix complete).
+// SPEC == true: touches only the scratch arrays and answers "would this op change the list?" -- false only when it is certain
+// that the new row is the one left out and every survivor keeps its slot (then list, distances and matrix stay as they are).
+template <class OP, int LPR, bool SPEC>
+__device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
+                      float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, uint8_t *QV,
+                      uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist)
+{
+
+        if (cnt < lm) {                                                            // mod.rs:469-471
+            if (SPEC) return true;
+            if (lane == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
+            cnt++;
+            F_WSYNC();
+            return false;
+        }
+        // pairs among the current list that the cache lacks: slot s against slots < s
+        if (SPEC && v < cnt) return true;
+        for (uint32_t sl = v < 1 ? 1 : v; sl < cnt; sl++) {
+            if (lane < sl) IDS[lane] = lid[lane];
+            f_park_w(fp, p.rows + (size_t)lid[sl] * p.pitch, lane, QV);
+            const float d = f_dist_batch<OP, LPR>(fp, QV, IDS, sl, lane);
+            if (lane < sl) M[sl * (sl - 1) / 2 + lane] = d;
+            ndist += sl;
+            F_WSYNC();
+        }
+        v = cnt;
+        // d(new row, slot) is evaluated LAZILY: a hub list (inner product on unnormalised rows sends thousands of back-links
+        // per batch to one list, all applied by this one wave in order) drops most newcomers after a few comparisons, so
+        // streaming all `cnt` neighbour rows per op would be a long serial chain of wasted loads.  Order of evaluation:
+        // the slots already accepted when the walk reaches the new row first (FUSED_RB at a time, stop at the first batch
+        // with a hit, like check_element_closer's early return), the remaining slots only if the new row stays in the list.
+        const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
+        if (lane < n) {
+            const float d = lane < cnt ? ld[lane] : new_d; uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) { const float dj = j < cnt ? ld[j] : new_d; rank += (dj < d) || (dj == d && j < lane); }
+            pos[rank] = lane < cnt ? lane : LC_SLOTS; sd[rank] = d;
+        }
+        F_WSYNC();
+        // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
+        uint32_t r = 0, ndc = 0, n_done = 0;      // n_done: how many entries of the evaluation order ORD have their nd[]
+        bool ordered = false; unsigned long long amask = 0ull;   // slots accepted so far
+        auto finish_nd = [&]() {                  // all remaining d(new, slot)
+            if (!ordered) {
+                if (lane < cnt) { IDS[lane] = lid[lane]; ORD[lane] = lane; }
+                f_park_w(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
+                ordered = true;
+            }
+            if (n_done < cnt) {
+                const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + n_done, cnt - n_done, lane);
+                if (lane < cnt - n_done) nd[ORD[n_done + lane]] = d;
+                ndist += cnt - n_done; n_done = cnt;
+            }
+            F_WSYNC();
+        };
+        for (uint32_t i = 0; i < n; i++) {
+            if (r >= lm) break;
+            const float ed = sd[i]; const uint32_t si = pos[i];
+            bool closer;
+            if (si == LC_SLOTS) {
+                // accepted slots first in the evaluation order
+                const bool acc = lane < cnt && ((amask >> lane) & 1ull) != 0ull;
+                const unsigned long long am = amask, below = (1ull << lane) - 1ull;
+                const uint32_t na = (uint32_t)__popcll(am);
+                if (lane < cnt) {
+                    const uint32_t o = acc ? (uint32_t)__popcll(am & below) : na + (uint32_t)__popcll(~am & below);
+                    IDS[o] = lid[lane]; ORD[o] = lane;
+                }
+                f_park_w(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
+                ordered = true;
+                bool hit = false;
+                constexpr uint32_t B = f_step_rows<LPR>();
+                for (uint32_t j0 = 0; j0 < na && !hit; j0 += B) {
+                    const uint32_t nb = na - j0 < B ? na - j0 : B;
+                    const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + j0, nb, lane);
+                    if (lane < nb) nd[ORD[j0 + lane]] = d;
+                    ndist += nb; n_done = j0 + nb;
+                    hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
+                }
+                closer = !hit;
+                if (SPEC && closer) return true;                                   // the new row enters the list
+                if (closer) finish_nd();                                           // later candidates are compared with the new row
+            } else {
+                bool hit = false;
+                if (lane < r) {
+                    const uint32_t sj = pos[sel[lane]];
+                    const float dij = sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)];
+                    hit = dij <= ed;                                               // mod.rs:333-335
+                }
+                closer = __ballot(hit) == 0ull;
+                if (closer) amask |= 1ull << si;
+            }
+            if (lane == 0) { if (closer) sel[r] = i; else dis[ndc] = i; }
+            if (closer) r++; else ndc++;
+            F_WSYNC();
+        }
+        if (lane == 0) for (uint32_t j = 0; j < ndc && r < lm; j++) sel[r++] = dis[j];   // mod.rs:300-305
+        r = __shfl(r, 0, 64);
+        F_WSYNC();
+        if (SPEC) {   // unchanged iff the new row is the one left out AND the survivors keep their slots, in order
+            const bool ok = lane >= r || pos[sel[lane]] == lane;
+            return __ballot(!ok) != 0ull;
+        }
+        {   // the new row's distances to every slot are needed only if it stays in the list
+            bool mine = lane < r && pos[sel[lane]] == LC_SLOTS;
+            if (__ballot(mine) != 0ull) finish_nd();
+        }
+        // surviving list and its pair matrix
+        if (lane < r) { const uint32_t sa = pos[sel[lane]]; lid2[lane] = sa == LC_SLOTS ? new_id : lid[sa]; ld2[lane] = sd[sel[lane]]; }
+        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) {
+            uint32_t a, b; tri_decode(idx, a, b);
+            const uint32_t sa = pos[sel[a]], sb = pos[sel[b]];
+            M2[idx] = sa == LC_SLOTS ? nd[sb] : (sb == LC_SLOTS ? nd[sa] : M[lc_tri(sa, sb)]);
+        }
+        F_WSYNC();
+        if (lane < r) { lid[lane] = lid2[lane]; ld[lane] = ld2[lane]; }
+        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) M[idx] = M2[idx];
+        cnt = r; v = r;
+        F_WSYNC();
+            return true;
+}
+
 template <class OP, int LPR>
 __global__ void __launch_bounds__(64, 4)
 k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
@@ -1153,112 +1289,8 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     __syncthreads();
     unsigned long long ndist = 0;
 
-    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
-        const uint32_t new_id = p.op_new[op]; const float new_d = p.op_d[op];
-        if (cnt < lm) {                                                            // mod.rs:469-471
-            if (lane == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
-            cnt++;
-            __syncthreads();
-            continue;
-        }
-        // pairs among the current list that the cache lacks: slot s against slots < s
-        for (uint32_t sl = v < 1 ? 1 : v; sl < cnt; sl++) {
-            if (lane < sl) IDS[lane] = lid[lane];
-            f_park(fp, p.rows + (size_t)lid[sl] * p.pitch, lane, QV);
-            const float d = f_dist_batch<OP, LPR>(fp, QV, IDS, sl, lane);
-            if (lane < sl) M[sl * (sl - 1) / 2 + lane] = d;
-            ndist += sl;
-            __syncthreads();
-        }
-        v = cnt;
-        // d(new row, slot) is evaluated LAZILY: a hub list (inner product on unnormalised rows sends thousands of back-links
-        // per batch to one list, all applied by this one wave in order) drops most newcomers after a few comparisons, so
-        // streaming all `cnt` neighbour rows per op would be a long serial chain of wasted loads.  Order of evaluation:
-        // the slots already accepted when the walk reaches the new row first (FUSED_RB at a time, stop at the first batch
-        // with a hit, like check_element_closer's early return), the remaining slots only if the new row stays in the list.
-        const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
-        if (lane < n) {
-            const float d = lane < cnt ? ld[lane] : new_d; uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; j++) { const float dj = j < cnt ? ld[j] : new_d; rank += (dj < d) || (dj == d && j < lane); }
-            pos[rank] = lane < cnt ? lane : LC_SLOTS; sd[rank] = d;
-        }
-        __syncthreads();
-        // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
-        uint32_t r = 0, ndc = 0, n_done = 0;      // n_done: how many entries of the evaluation order ORD have their nd[]
-        bool ordered = false; unsigned long long amask = 0ull;   // slots accepted so far
-        auto finish_nd = [&]() {                  // all remaining d(new, slot)
-            if (!ordered) {
-                if (lane < cnt) { IDS[lane] = lid[lane]; ORD[lane] = lane; }
-                f_park(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
-                ordered = true;
-            }
-            if (n_done < cnt) {
-                const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + n_done, cnt - n_done, lane);
-                if (lane < cnt - n_done) nd[ORD[n_done + lane]] = d;
-                ndist += cnt - n_done; n_done = cnt;
-            }
-            __syncthreads();
-        };
-        for (uint32_t i = 0; i < n; i++) {
-            if (r >= lm) break;
-            const float ed = sd[i]; const uint32_t si = pos[i];
-            bool closer;
-            if (si == LC_SLOTS) {
-                // accepted slots first in the evaluation order
-                const bool acc = lane < cnt && ((amask >> lane) & 1ull) != 0ull;
-                const unsigned long long am = amask, below = (1ull << lane) - 1ull;
-                const uint32_t na = (uint32_t)__popcll(am);
-                if (lane < cnt) {
-                    const uint32_t o = acc ? (uint32_t)__popcll(am & below) : na + (uint32_t)__popcll(~am & below);
-                    IDS[o] = lid[lane]; ORD[o] = lane;
-                }
-                f_park(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
-                ordered = true;
-                bool hit = false;
-                constexpr uint32_t B = f_step_rows<LPR>();
-                for (uint32_t j0 = 0; j0 < na && !hit; j0 += B) {
-                    const uint32_t nb = na - j0 < B ? na - j0 : B;
-                    const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + j0, nb, lane);
-                    if (lane < nb) nd[ORD[j0 + lane]] = d;
-                    ndist += nb; n_done = j0 + nb;
-                    hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
-                }
-                closer = !hit;
-                if (closer) finish_nd();                                           // later candidates are compared with the new row
-            } else {
-                bool hit = false;
-                if (lane < r) {
-                    const uint32_t sj = pos[sel[lane]];
-                    const float dij = sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)];
-                    hit = dij <= ed;                                               // mod.rs:333-335
-                }
-                closer = __ballot(hit) == 0ull;
-                if (closer) amask |= 1ull << si;
-            }
-            if (lane == 0) { if (closer) sel[r] = i; else dis[ndc] = i; }
-            if (closer) r++; else ndc++;
-            __syncthreads();
-        }
-        if (lane == 0) for (uint32_t j = 0; j < ndc && r < lm; j++) sel[r++] = dis[j];   // mod.rs:300-305
-        r = __shfl(r, 0, 64);
-        __syncthreads();
-        {   // the new row's distances to every slot are needed only if it stays in the list
-            bool mine = lane < r && pos[sel[lane]] == LC_SLOTS;
-            if (__ballot(mine) != 0ull) finish_nd();
-        }
-        // surviving list and its pair matrix
-        if (lane < r) { const uint32_t sa = pos[sel[lane]]; lid2[lane] = sa == LC_SLOTS ? new_id : lid[sa]; ld2[lane] = sd[sel[lane]]; }
-        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) {
-            uint32_t a, b; tri_decode(idx, a, b);
-            const uint32_t sa = pos[sel[a]], sb = pos[sel[b]];
-            M2[idx] = sa == LC_SLOTS ? nd[sb] : (sb == LC_SLOTS ? nd[sa] : M[lc_tri(sa, sb)]);
-        }
-        __syncthreads();
-        if (lane < r) { lid[lane] = lid2[lane]; ld[lane] = ld2[lane]; }
-        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) M[idx] = M2[idx];
-        cnt = r; v = r;
-        __syncthreads();
-    }
+    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++)
+        (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist);
     if (lane < cnt) {
         gl_ids[lane] = lid[lane]; gl_d[lane] = ld[lane];
         p.out_ids[(size_t)g * 2u * p.m + lane] = lid[lane]; p.out_d[(size_t)g * 2u * p.m + lane] = ld[lane];
