@@ -964,6 +964,7 @@ struct LinksParams {
     const uint8_t *rows; uint32_t pitch, m;
     uint32_t *l0_ids; float *l0_d; uint16_t *l0_cnt; const uint32_t *up_block; uint32_t *up_ids; float *up_d; uint16_t *up_cnt;
     uint32_t n_groups; const uint32_t *target, *layer, *op_off, *op_new; const float *op_d;
+    const uint32_t *gmap;   // launch index -> group (nullptr: identity); the groups of a batch are split between k_links_cached and k_links_hub
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; unsigned long long *n_pairs;
     uint32_t dbg;   // timing experiments only (HX_LK_DBG): 1 skip pair math, 2 skip row loads, 4 skip select
 };
@@ -1272,8 +1273,8 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     float *DSC = (float *)(IDS + 64);
     uint8_t *QV = (uint8_t *)(DSC + 64);
     const uint32_t lane = threadIdx.x;
-    const uint32_t g = blockIdx.x;
-    if (g >= p.n_groups) return;
+    if (blockIdx.x >= p.n_groups) return;
+    const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
     FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u; fp.dsc = DSC;
     const uint32_t target = p.target[g], layer = p.layer[g];
     const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
@@ -1303,6 +1304,92 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     if (lane == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
 }
 
+// =================================================================================================
+// K4c k_links_hub: the same per-list work for a list that receives a LONG chain of back-links in one batch (inner product on
+//   unnormalised rows: thousands of ops for one hub list, which one wave would apply one after the other).  Almost all of a
+//   hub's newcomers are left out again, so HUB_W waves evaluate the next HUB_W ops speculatively, each against the
+//   current list (lc_op<SPEC>: scratch only); the ops before the first one that would change the list are no-ops by
+//   construction, that one is applied by wave 0 with the ordinary code, and the rest are re-evaluated.  Same result as the
+//   one-wave kernel, op for op.
+// =================================================================================================
+#define HUB_W 4
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64 * HUB_W, 1)
+k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t nchb = ((p.pitch + 1023u) / 1024u) * 1024u;
+    // shared: M[528] M2[528] lid[40] ld[40] lid2[40] ld2[40] ctl[16]; per wave: nd pos sd sel dis ORD [40 each] IDS[64] DSC[64] QV[nchb]
+    float *M = (float *)lds, *M2 = M + 528;
+    uint32_t *lid = (uint32_t *)(M2 + 528); float *ld = (float *)(lid + 40);
+    uint32_t *lid2 = (uint32_t *)(ld + 40); float *ld2 = (float *)(lid2 + 40);
+    uint32_t *ctl = (uint32_t *)(ld2 + 40);
+    uint8_t *wbase = (uint8_t *)(ctl + 16) + (size_t)wave * ((40 * 6 + 64 + 64) * 4 + nchb);
+    float *nd = (float *)wbase; uint32_t *pos = (uint32_t *)(nd + 40); float *sd = (float *)(pos + 40);
+    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *ORD = dis + 40, *IDS = ORD + 40;
+    float *DSC = (float *)(IDS + 64);
+    uint8_t *QV = (uint8_t *)(DSC + 64);
+    if (blockIdx.x >= p.n_groups) return;
+    const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
+    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u; fp.dsc = DSC;
+    const uint32_t target = p.target[g], layer = p.layer[g];
+    const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
+    uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
+    if (layer == 0) { gl_ids = p.l0_ids + (size_t)target * 2u * p.m; gl_d = p.l0_d + (size_t)target * 2u * p.m; gl_cnt = p.l0_cnt + target; }
+    else { const uint32_t blk = p.up_block[target] + layer - 1; gl_ids = p.up_ids + (size_t)blk * p.m; gl_d = p.up_d + (size_t)blk * p.m; gl_cnt = p.up_cnt + blk; }
+    const bool cached = layer == 0 && lm == LC_SLOTS && pm != nullptr;
+    uint32_t cnt = *gl_cnt;
+    uint32_t v = cached ? pm_valid[target] : 0u;
+    if (v > cnt) v = 0;
+    if (threadIdx.x < cnt) { lid[threadIdx.x] = gl_ids[threadIdx.x]; ld[threadIdx.x] = gl_d[threadIdx.x]; }
+    if (v > 1) { const float *src = pm + (size_t)target * LC_TRI; for (uint32_t i = threadIdx.x; i < v * (v - 1) / 2; i += 64 * HUB_W) M[i] = src[i]; }
+    const uint32_t op_end = p.op_off[g + 1];
+    if (threadIdx.x == 0) { ctl[0] = p.op_off[g]; ctl[1] = cnt; ctl[2] = v; ctl[3] = 0; }   // next op, |list|, cached slots, list is in select order
+    unsigned long long ndist = 0;
+    for (;;) {
+        __syncthreads();
+        const uint32_t op = ctl[0]; cnt = ctl[1]; v = ctl[2]; const bool canon = ctl[3] != 0;
+        if (op >= op_end) break;
+        if (!canon || cnt < lm || v < cnt) {                       // appends, the first prune, missing pairs: the ordinary path, one op
+            __syncthreads();
+            if (wave == 0) {
+                const bool pruned = lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist);
+                if (lane == 0) { ctl[0] = op + 1u; ctl[1] = cnt; ctl[2] = v; if (pruned) ctl[3] = 1u; }
+            }
+            continue;
+        }
+        const uint32_t nv = op_end - op < HUB_W ? op_end - op : HUB_W;   // ops evaluated this round
+        bool changed = false;
+        if (wave < nv) {
+            uint32_t c2 = cnt, v2 = v;
+            changed = lc_op<OP, LPR, true>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, c2, v2, lm, p.op_new[op + wave], p.op_d[op + wave], lane, ndist);
+        }
+        if (lane == 0) ctl[4 + wave] = changed ? 1u : 0u;
+        __syncthreads();
+        uint32_t first = nv;
+        for (uint32_t w = 0; w < nv; w++) if (ctl[4 + w]) { first = w; break; }
+        __syncthreads();
+        if (first == nv) { if (threadIdx.x == 0) ctl[0] = op + nv; continue; }
+        if (wave == 0) {
+            (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op + first], p.op_d[op + first], lane, ndist);
+            if (lane == 0) { ctl[0] = op + first + 1u; ctl[1] = cnt; ctl[2] = v; }
+        }
+    }
+    cnt = ctl[1]; v = ctl[2];
+    if (threadIdx.x < cnt) {
+        gl_ids[threadIdx.x] = lid[threadIdx.x]; gl_d[threadIdx.x] = ld[threadIdx.x];
+        p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x];
+    }
+    if (cached) {
+        float *dst = pm + (size_t)target * LC_TRI;
+        for (uint32_t i = threadIdx.x; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64 * HUB_W) dst[i] = M[i];
+        if (threadIdx.x == 0) pm_valid[target] = (uint8_t)v;
+    }
+    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; }
+    if (lane == 0) atomicAdd(p.n_pairs, ndist);
+}
+
 template <class OP, int LPR>
 static hipError_t launch_links_cached_lpr(hx_engine *e, const LinksParams &p)
 {
@@ -1310,6 +1397,21 @@ static hipError_t launch_links_cached_lpr(hx_engine *e, const LinksParams &p)
     const size_t lds = (528 * 2 + 40 * 11 + 64 + 64) * 4 + nch * 1024;
     hipLaunchKernelGGL((k_links_cached<OP, LPR>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
     return hipGetLastError();
+}
+template <class OP, int LPR>
+static hipError_t launch_links_hub_lpr(hx_engine *e, const LinksParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (528 * 2 + 40 * 4 + 16) * 4 + (size_t)HUB_W * ((40 * 6 + 64 + 64) * 4 + nch * 1024);
+    hipLaunchKernelGGL((k_links_hub<OP, LPR>), dim3(p.n_groups), dim3(64 * HUB_W), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    return hipGetLastError();
+}
+template <class OP>
+static hipError_t launch_links_hub(hx_engine *e, const LinksParams &p)
+{
+    if (e->pitch <= 128) return launch_links_hub_lpr<OP, 8>(e, p);
+    if (e->pitch <= 512) return launch_links_hub_lpr<OP, 32>(e, p);
+    return launch_links_hub_lpr<OP, 64>(e, p);
 }
 template <class OP>
 static hipError_t launch_links_cached(hx_engine *e, const LinksParams &p)
@@ -1371,6 +1473,7 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     const size_t o_off = o; o += al16(((size_t)n_groups + 1) * 4);
     const size_t o_new = o; o += al16((size_t)n_ops * 4);
     const size_t o_od = o; o += al16((size_t)n_ops * 4);
+    const size_t o_gmap = o; o += al16((size_t)n_groups * 4);   // launch order: hub lists first, then the rest
     const size_t in_bytes = o;
     const size_t o_cnt = o; o += al16((size_t)n_groups * 4);
     const size_t o_ids = o; o += al16((size_t)n_groups * lm0 * 4);
@@ -1389,6 +1492,15 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     memcpy(h + o_tg, target, (size_t)n_groups * 4); memcpy(h + o_ly, layer, (size_t)n_groups * 4);
     memcpy(h + o_off, op_off, ((size_t)n_groups + 1) * 4);
     memcpy(h + o_new, op_new, (size_t)n_ops * 4); memcpy(h + o_od, op_d, (size_t)n_ops * 4);
+    uint32_t n_hub = 0;
+    {   // lists with a long chain of ops go to the speculative multi-wave kernel (k_links_hub); HX_HUB_MIN=0 disables it
+        static const uint32_t hub_min = getenv("HX_HUB_MIN") ? (uint32_t)atoi(getenv("HX_HUB_MIN")) : 48u;
+        uint32_t *gm = (uint32_t *)(h + o_gmap);
+        if (cached_kernel && hub_min) for (uint32_t g = 0; g < n_groups; g++) if (op_off[g + 1] - op_off[g] >= hub_min) gm[n_hub++] = g;
+        uint32_t k = n_hub;
+        if (n_hub) { for (uint32_t g = 0; g < n_groups; g++) if (op_off[g + 1] - op_off[g] < hub_min) gm[k++] = g; }
+        else for (uint32_t g = 0; g < n_groups; g++) gm[g] = g;
+    }
     HX_HIP(this, hipMemcpyAsync(mr.d_lk, h, in_bytes, hipMemcpyHostToDevice, stream));
     LinksParams p;
     p.rows = d_rows; p.pitch = (uint32_t)pitch; p.m = mr.m;
@@ -1397,15 +1509,28 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     p.op_off = (const uint32_t *)(mr.d_lk + o_off); p.op_new = (const uint32_t *)(mr.d_lk + o_new); p.op_d = (const float *)(mr.d_lk + o_od);
     p.out_ids = (uint32_t *)(mr.d_lk + o_ids); p.out_d = (float *)(mr.d_lk + o_d); p.out_cnt = (uint32_t *)(mr.d_lk + o_cnt);
     p.n_pairs = (unsigned long long *)(mr.d_lk + o_ctr);
+    p.gmap = nullptr;
     { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
     if (cached_kernel) {
+        if (n_hub) {
+            LinksParams ph = p; ph.n_groups = n_hub; ph.gmap = (const uint32_t *)(mr.d_lk + o_gmap);
+#define F32C(K) ls = launch_links_hub<OpF32<K>>(this, ph)
+#define F16C(K) ls = launch_links_hub<OpF16<K>>(this, ph)
+            HX_DISPATCH(this, F32C, F16C, ls = launch_links_hub<OpHamming>(this, ph), ls = launch_links_hub<OpJaccard>(this, ph));
+#undef F32C
+#undef F16C
+            HX_HIP(this, ls);
+            p.gmap = (const uint32_t *)(mr.d_lk + o_gmap) + n_hub; p.n_groups = n_groups - n_hub;
+        }
+        if (p.n_groups) {
 #define F32C(K) ls = launch_links_cached<OpF32<K>>(this, p)
 #define F16C(K) ls = launch_links_cached<OpF16<K>>(this, p)
         HX_DISPATCH(this, F32C, F16C, ls = launch_links_cached<OpHamming>(this, p), ls = launch_links_cached<OpJaccard>(this, p));
 #undef F32C
 #undef F16C
+        }
     } else {
 #define F32C(K) ls = launch_links<OpF32<K>>(this, p)
 #define F16C(K) ls = launch_links<OpF16<K>>(this, p)

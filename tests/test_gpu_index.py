@@ -515,3 +515,26 @@ def test_iterative_scan_on_device_equals_lockstep_and_oracle(dt, metric, dim, n,
             assert a[0][q, :a[2][q]].tolist() == want, (c, max_tuples, q)
     ix.close()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,dim", [(hx.F32, 24), (hx.F16, 40)])
+def test_hub_lists_inner_product_long_back_link_chains(dt, dim):
+    """Inner product on rows of very different norms: a few high-norm rows are everybody's neighbour, so single lists receive
+    hundreds of back-links per batch (k_links_hub: ops evaluated speculatively by several waves, applied in order).  The graph
+    must still equal the oracle's, list by list, distance bits included."""
+    rng = np.random.default_rng(31)
+    n, m, efc, batch = 5000, 16, 64, 2048
+    base = rng.random((n, dim), dtype=np.float32)
+    scale = np.exp(rng.normal(0.0, 1.2, n)).astype(np.float32)[:, None]         # log-normal norms: strong hubs
+    rows = (base * scale).astype(np.float32)
+    if dt == hx.F16:
+        rows = rows.astype(np.float16).view(np.uint16)
+    levels = hx.draw_levels(n, m, seed=31)
+    e, ix, _, o, _ = build_both(dt, hx.NEG_IP, dim, rows, levels, m, efc, batch)
+    prof = ix.profile()
+    assert prof["links_max_chain"] >= 200, prof["links_max_chain"]                 # the hub path was exercised
+    assert ix.fused_stats()["redone"] == 0
+    assert_same_graph(ix, o, n)
+    ix.close()
+    e.close()
