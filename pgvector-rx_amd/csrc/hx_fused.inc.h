@@ -1312,7 +1312,9 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
 //   construction, that one is applied by wave 0 with the ordinary code, and the rest are re-evaluated.  Same result as the
 //   one-wave kernel, op for op.
 // =================================================================================================
-#define HUB_W 4
+#ifndef HUB_W
+#define HUB_W 8
+#endif
 template <class OP, int LPR>
 __global__ void __launch_bounds__(64 * HUB_W, 1)
 k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
@@ -1403,6 +1405,12 @@ static hipError_t launch_links_hub_lpr(hx_engine *e, const LinksParams &p)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
     const size_t lds = (528 * 2 + 40 * 4 + 16) * 4 + (size_t)HUB_W * ((40 * 6 + 64 + 64) * 4 + nch * 1024);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t st = hipFuncSetAttribute((const void *)k_links_hub<OP, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (st != hipSuccess) return st;
+        attr_set = true;
+    }
     hipLaunchKernelGGL((k_links_hub<OP, LPR>), dim3(p.n_groups), dim3(64 * HUB_W), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
     return hipGetLastError();
 }
