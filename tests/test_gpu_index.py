@@ -538,3 +538,54 @@ def test_hub_lists_inner_product_long_back_link_chains(dt, dim):
     assert_same_graph(ix, o, n)
     ix.close()
     e.close()
+
+
+def _random_cases():
+    rng = np.random.default_rng(2026)
+    cases = []
+    for i in range(28):
+        dt = [hx.F32, hx.F16, hx.BIT][int(rng.integers(0, 3))]
+        if dt == hx.BIT:
+            metric = [hx.HAMMING, hx.JACCARD][int(rng.integers(0, 2))]
+            dim = int(rng.choice([9, 52, 64, 100, 1024, 1500, 4100]))       # payloads on both sides of 128 B / 512 B
+        else:
+            metric = [hx.L2SQ, hx.NEG_IP, hx.L1][int(rng.integers(0, 3))]
+            dim = int(rng.choice([1, 3, 17, 31, 32, 33, 64, 127, 129, 200, 257, 300]))
+        m = int(rng.choice([2, 3, 5, 8, 12, 16]))                              # the device kernels serve m <= 16 (lists of <= 32)
+        efc = int(rng.choice([2 * m, 2 * m + 7, 40, 64]))
+        efc = max(efc, 2 * m)
+        n = int(rng.integers(250, 900))
+        batch = int(rng.choice([1, 7, 64, 300]))
+        dup = int(rng.choice([0, 0, 11]))
+        cases.append((i, dt, metric, dim, m, efc, n, batch, dup))
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _random_cases(), ids=lambda c: "r%d-t%d-m%d-d%d-M%d-e%d-n%d-b%d-dup%d" % c)
+def test_randomized_shapes_match_oracle(case):
+    """A seeded sweep over dtype x metric x dim x m x ef_construction x batch x duplicates: graph identity with the oracle,
+    then the same top-k and the same relaxed iterative scan as the oracle, all through the device-resident kernels."""
+    i, dt, metric, dim, m, efc, n, batch, dup = case
+    rng = np.random.default_rng(1000 + i)
+    rows = make_rows(dt, n, dim, rng)
+    if dup:
+        for j in range(dup, n, dup):
+            rows[j] = rows[j - 1]
+    levels = hx.draw_levels(n, m, seed=1000 + i)
+    e, ix, _, o, _ = build_both(dt, metric, dim, rows, levels, m, efc, batch)
+    assert ix.fused_stats()["redone"] <= int((levels >= 8).sum())      # only rows above the kernel's 8 layers go to the lock-step path
+    assert_same_graph(ix, o, n)
+    nq, efs, k = 8, max(10, m), 6
+    qs = make_rows(dt, nq, dim, rng)
+    e.set_queries(qs)
+    tids, d, el, cnt = ix.search(nq, efs, k)
+    passes = (np.arange(n) % 3 == 0).astype(np.uint8)
+    it = ix.search_iterative(nq, efs, 1, 500, 5, passes)
+    for q in range(nq):
+        want = [t for t, _, _ in o.scan(qs[q], ef_search=efs, limit=k)]
+        assert tids[q, :cnt[q]].tolist() == want
+        wit = [t for t, _, _ in o.scan(qs[q], ef_search=efs, iterative=orc.ITER_RELAXED, max_scan_tuples=500) if passes[t]][:5]
+        assert it[0][q, :it[2][q]].tolist() == wit
+    ix.close()
+    e.close()
