@@ -330,7 +330,7 @@ template <int LPR> __device__ __forceinline__ constexpr uint32_t f_step_rows() {
 // distances from the vector parked at `qv` (LDS) to rows ids[0..n) (LDS); lane j (< 64) returns d(q, ids[j]); n <= 64.
 // FUSED_RB rows x FUSED_CG 1-KiB chunks are requested at once (one HBM latency per row batch at d <= 768 f32), then
 // consumed chunk by chunk in ascending order -- the canonical per-lane order.
-template <class OP, int LPR>
+template <class OP, int LPR, int RB = FUSED_RB>
 __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
     if constexpr (LPR < 64) return f_dist_small<OP, LPR>(p, qv, ids, n, lane);
@@ -338,22 +338,22 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
     unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
 #define FD_TICK(k) do { if (tk) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[k] += (uint32_t)(t_ - tq); tq = t_; } } while (0)
     const uint32_t loff = lane * 16u;
-    for (uint32_t j0 = 0; j0 < n; j0 += FUSED_RB) {
-        const uint8_t *rp[FUSED_RB];
+    for (uint32_t j0 = 0; j0 < n; j0 += RB) {
+        const uint8_t *rp[RB];
 #pragma unroll
-        for (int r = 0; r < FUSED_RB; r++) rp[r] = p.rows + (size_t)ids[j0 + r < n ? j0 + r : j0] * p.pitch + loff;
-        typename OP::acc_t acc[FUSED_RB];
+        for (int r = 0; r < RB; r++) rp[r] = p.rows + (size_t)ids[j0 + r < n ? j0 + r : j0] * p.pitch + loff;
+        typename OP::acc_t acc[RB];
 #pragma unroll
-        for (int r = 0; r < FUSED_RB; r++) OP::init(acc[r]);
+        for (int r = 0; r < RB; r++) OP::init(acc[r]);
 #pragma unroll 1
         for (uint32_t c0 = 0; c0 < p.nch; c0 += FUSED_CG) {
-            u4 rv[FUSED_RB][FUSED_CG];
+            u4 rv[RB][FUSED_CG];
 #pragma unroll
             for (int k = 0; k < FUSED_CG; k++) {
                 const uint32_t off = (c0 + k) * 1024u;
                 const bool in = c0 + k < p.nch && off + loff < p.pitch;
 #pragma unroll
-                for (int r = 0; r < FUSED_RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (in) v = *(const u4 *)(rp[r] + off); rv[r][k] = v; }
+                for (int r = 0; r < RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (in) v = *(const u4 *)(rp[r] + off); rv[r][k] = v; }
             }
             FD_TICK(9);                                   // addresses + load issue
             if (tk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -363,14 +363,14 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
                 if (c0 + k < p.nch) {
                     const u4 q = *(const u4 *)(qv + (c0 + k) * 1024u + loff);
 #pragma unroll
-                    for (int r = 0; r < FUSED_RB; r++) OP::add(acc[r], q, rv[r][k]);
+                    for (int r = 0; r < RB; r++) OP::add(acc[r], q, rv[r][k]);
                 }
             }
             if (tk) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             FD_TICK(11);                                  // arithmetic
         }
 #pragma unroll
-        for (int r = 0; r < FUSED_RB; r++) {
+        for (int r = 0; r < RB; r++) {
             const float d = OP::template finish<64>(acc[r]);
             if (j0 + r < n && lane == j0 + r) mine = d;
         }
@@ -1129,6 +1129,9 @@ k_links(const LinksParams p)
 //   row by row.  Cached values are the very bits a recomputation would give, so results equal k_links / the lock-step path.
 // =================================================================================================
 #define LC_SLOTS 32
+#ifndef LC_RB
+#define LC_RB FUSED_RB         /* rows in flight when a whole list is streamed; 8 was measured slower (spills at 4 waves/SIMD) */
+#endif
 #define LC_TRI (LC_SLOTS * (LC_SLOTS - 1) / 2)     /* 496 */
 __device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > j ? i * (i - 1) / 2 + j : j * (j - 1) / 2 + i; }
 
@@ -1140,8 +1143,11 @@ __device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > 
 template <class OP, int LPR, bool SPEC>
 __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
                       float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, uint8_t *QV,
-                      uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist)
+                      uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist, unsigned long long *tk = nullptr)
 {
+    unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
+#define LC_TICK(k) do { if (tk) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[k] += t_ - tq; tq = t_; } } while (0)
+
 
         if (cnt < lm) {                                                            // mod.rs:469-471
             if (SPEC) return true;
@@ -1155,27 +1161,34 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
         for (uint32_t sl = v < 1 ? 1 : v; sl < cnt; sl++) {
             if (lane < sl) IDS[lane] = lid[lane];
             f_park_w(fp, p.rows + (size_t)lid[sl] * p.pitch, lane, QV);
-            const float d = f_dist_batch<OP, LPR>(fp, QV, IDS, sl, lane);
+            const float d = f_dist_batch<OP, LPR, LC_RB>(fp, QV, IDS, sl, lane);
             if (lane < sl) M[sl * (sl - 1) / 2 + lane] = d;
             ndist += sl;
             F_WSYNC();
         }
         v = cnt;
+        LC_TICK(0);                                                                // missing pairs of the matrix
         // d(new row, slot) is evaluated LAZILY: a hub list (inner product on unnormalised rows sends thousands of back-links
         // per batch to one list, all applied by this one wave in order) drops most newcomers after a few comparisons, so
         // streaming all `cnt` neighbour rows per op would be a long serial chain of wasted loads.  Order of evaluation:
         // the slots already accepted when the walk reaches the new row first (FUSED_RB at a time, stop at the first batch
         // with a hit, like check_element_closer's early return), the remaining slots only if the new row stays in the list.
         const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
-        if (lane < n) {
+        {   // rank sort: every lane compares its distance with lane j's, read through the scalar unit (no LDS traffic)
             const float d = lane < cnt ? ld[lane] : new_d; uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; j++) { const float dj = j < cnt ? ld[j] : new_d; rank += (dj < d) || (dj == d && j < lane); }
-            pos[rank] = lane < cnt ? lane : LC_SLOTS; sd[rank] = d;
+            const unsigned int dbits = __builtin_bit_cast(unsigned int, d);
+            for (uint32_t j = 0; j < n; j++) {
+                const float dj = __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_readlane((int)dbits, (int)j));
+                rank += (dj < d) || (dj == d && j < lane);
+            }
+            if (lane < n) { pos[rank] = lane < cnt ? lane : LC_SLOTS; sd[rank] = d; }
         }
         F_WSYNC();
+        LC_TICK(1);                                                                // sort
         // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
         uint32_t r = 0, ndc = 0, n_done = 0;      // n_done: how many entries of the evaluation order ORD have their nd[]
         bool ordered = false; unsigned long long amask = 0ull;   // slots accepted so far
+        uint32_t my_slot = 0;                      // lane j: slot of the j-th accepted candidate
         auto finish_nd = [&]() {                  // all remaining d(new, slot)
             if (!ordered) {
                 if (lane < cnt) { IDS[lane] = lid[lane]; ORD[lane] = lane; }
@@ -1183,7 +1196,7 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
                 ordered = true;
             }
             if (n_done < cnt) {
-                const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + n_done, cnt - n_done, lane);
+                const float d = f_dist_batch<OP, LPR, LC_RB>(fp, QV, IDS + n_done, cnt - n_done, lane);
                 if (lane < cnt - n_done) nd[ORD[n_done + lane]] = d;
                 ndist += cnt - n_done; n_done = cnt;
             }
@@ -1194,6 +1207,7 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
             const float ed = sd[i]; const uint32_t si = pos[i];
             bool closer;
             if (si == LC_SLOTS) {
+                LC_TICK(2);                                                        // walk so far
                 // accepted slots first in the evaluation order
                 const bool acc = lane < cnt && ((amask >> lane) & 1ull) != 0ull;
                 const unsigned long long am = amask, below = (1ull << lane) - 1ull;
@@ -1214,18 +1228,20 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
                     hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
                 }
                 closer = !hit;
+                LC_TICK(3);                                                        // lazy distances of the new row
                 if (SPEC && closer) return true;                                   // the new row enters the list
                 if (closer) finish_nd();                                           // later candidates are compared with the new row
             } else {
                 bool hit = false;
                 if (lane < r) {
-                    const uint32_t sj = pos[sel[lane]];
+                    const uint32_t sj = my_slot;                                   // slot of the lane-th accepted candidate (== pos[sel[lane]])
                     const float dij = sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)];
                     hit = dij <= ed;                                               // mod.rs:333-335
                 }
                 closer = __ballot(hit) == 0ull;
                 if (closer) amask |= 1ull << si;
             }
+            if (closer && lane == r) my_slot = si;
             if (lane == 0) { if (closer) sel[r] = i; else dis[ndc] = i; }
             if (closer) r++; else ndc++;
             F_WSYNC();
@@ -1233,6 +1249,7 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
         if (lane == 0) for (uint32_t j = 0; j < ndc && r < lm; j++) sel[r++] = dis[j];   // mod.rs:300-305
         r = __shfl(r, 0, 64);
         F_WSYNC();
+        LC_TICK(2);
         if (SPEC) {   // unchanged iff the new row is the one left out AND the survivors keep their slots, in order
             const bool ok = lane >= r || pos[sel[lane]] == lane;
             return __ballot(!ok) != 0ull;
@@ -1253,7 +1270,9 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
         for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) M[idx] = M2[idx];
         cnt = r; v = r;
         F_WSYNC();
+        LC_TICK(4);                                                                // remaining distances + list / matrix rebuild
             return true;
+#undef LC_TICK
 }
 
 template <class OP, int LPR>
@@ -1290,8 +1309,10 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     __syncthreads();
     unsigned long long ndist = 0;
 
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+    const bool tm = (p.dbg & 8u) != 0; const unsigned long long tk0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++)
-        (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist);
+        (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr);
     if (lane < cnt) {
         gl_ids[lane] = lid[lane]; gl_d[lane] = ld[lane];
         p.out_ids[(size_t)g * 2u * p.m + lane] = lid[lane]; p.out_d[(size_t)g * 2u * p.m + lane] = ld[lane];
@@ -1302,6 +1323,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
         if (lane == 0) pm_valid[target] = (uint8_t)v;
     }
     if (lane == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
+    if (tm && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk[5] = __builtin_amdgcn_s_memtime() - tk0; for (int i = 0; i < 6; i++) atomicAdd(p.n_pairs + 1 + i, tk[i]); }
 }
 
 // =================================================================================================
@@ -1553,6 +1575,7 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     HX_HIP(this, hipStreamSynchronize(stream));
     *out_cnt = (const uint32_t *)(h + o_cnt); *out_ids = (const uint32_t *)(h + o_ids); *out_d = (const float *)(h + o_d);
     unsigned long long np; memcpy(&np, h + o_ctr, 8);
+    if (p.dbg & 8u) { unsigned long long t[7]; memcpy(t, h + o_ctr, 56); fprintf(stderr, "[hx] k_links_cached groups %u ops %u: ticks matrix-fill %llu sort %llu walk %llu lazy-nd %llu rebuild %llu; whole kernel per wave %llu\n", n_groups, n_ops, t[1], t[2], t[3], t[4], t[5], t[6]); }
     if (n_pairs) *n_pairs = np;
     if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
     return HX_OK;
