@@ -1636,7 +1636,7 @@ static hipError_t launch_fused_mode(hx_engine *e, const FusedParams &p, uint32_t
 // [ntasks][FUSED_MAXL][2m], out_cnt [ntasks][FUSED_MAXL].  status[ntasks].  All host pointers.
 int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                          uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                         uint64_t counts[2], const HxFusedIter *it, HxFusedView *view)
+                         uint64_t counts[2], const HxFusedIter *it, HxFusedView *view, uint32_t roomy)
 {
     HxMirror &mr = mirror;
     if (ntasks == 0) return HX_OK;
@@ -1649,7 +1649,8 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     // (the largest heap seen on 1M x 768 builds was 1552 entries at ef = 200); beyond FUSED_CCAP a task reports
     // FS_OVERFLOW and is re-run by the lock-step path
     const size_t nch_ = (pitch + 1023) / 1024;
-    const uint32_t ccap = FUSED_CCAP;
+    if (roomy < 1 || mode == 2) roomy = 1;
+    const uint32_t ccap = FUSED_CCAP * roomy;
     uint32_t clds = mode == 1 ? 1024u : 512u;
     uint32_t disc_lds = mode == 2 ? 512u : 0u;
     uint32_t iter_per_cu = 14u;
@@ -1663,6 +1664,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     { const char *pv = getenv(mode == 0 ? "HX_QUERY_PER_CU" : "HX_INSERT_PER_CU"); if (mode != 2 && pv && atoi(pv) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(pv)); }   // tuning knob
     uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
     uint64_t vis_words = 4096; while (vis_words < (uint64_t)ef * 2 * mr.m * 2 + 1024) vis_words <<= 1;   // >= 2x the ids a search can touch at its usual ~ef expansions
+    vis_words *= roomy;
     uint64_t disc_stride = 0;
     if (mode == 2) {
         // an iterative scan keeps its visited set and `discarded` heap across resumes: sized for max_scan_tuples (a query that
@@ -1690,7 +1692,15 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         HX_HIP(this, hipMemcpyAsync(mr.d_emask, it->emask, (size_t)it->n_elems * 2, hipMemcpyHostToDevice, stream));
     }
     if (!mr.d_spill) HX_HIP(this, hipMalloc((void **)&mr.d_spill, (size_t)256 * 16 * FUSED_CCAP * 8));
-    if ((uint64_t)grid * vis_words > mr.cap_vis) {
+    uint32_t *vis_ptr = nullptr; void *spill_ptr = mr.d_spill;
+    if (roomy > 1) {   // a retry launch of a few overflowed tasks: private, larger tables sized for exactly this grid
+        grid = std::min<uint32_t>(grid, 1024u);
+        const size_t need_sp = (size_t)grid * ccap * 8; const uint64_t need_vis = (uint64_t)grid * vis_words;
+        if (need_sp > mr.cap_spill_big) { if (mr.d_spill_big) (void)hipFree(mr.d_spill_big); mr.d_spill_big = nullptr; mr.cap_spill_big = 0; HX_HIP(this, hipMalloc(&mr.d_spill_big, need_sp)); mr.cap_spill_big = need_sp; }
+        if (need_vis > mr.cap_vis_big) { if (mr.d_vis_big) (void)hipFree(mr.d_vis_big); mr.d_vis_big = nullptr; mr.cap_vis_big = 0; HX_HIP(this, hipMalloc((void **)&mr.d_vis_big, need_vis * 4)); mr.cap_vis_big = need_vis; }
+        vis_ptr = mr.d_vis_big; spill_ptr = mr.d_spill_big;
+    }
+    if (roomy == 1 && (uint64_t)grid * vis_words > mr.cap_vis) {
         if (mr.d_vis) (void)hipFree(mr.d_vis);
         mr.d_vis = nullptr; mr.cap_vis = 0;
         const uint64_t n = (uint64_t)(mode == 2 ? grid : 256u * 16u) * vis_words;
@@ -1733,9 +1743,9 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     p.ef = ef; p.k = k; p.ccap = ccap; p.clds = clds;
     p.iter_mode = 0; p.limit = k; p.max_tuples = 0; p.emask = nullptr; p.disc = nullptr; p.disc_stride = 0; p.disc_lds = disc_lds; p.out_tix = (uint32_t *)(mr.d_io + o_tix);
     if (mode == 2) { p.iter_mode = (uint32_t)it->iter_mode; p.max_tuples = it->max_tuples; p.emask = mr.d_emask; p.disc = (unsigned long long *)mr.d_disc; p.disc_stride = (uint32_t)disc_stride; }
-    p.spill = (uint2 *)mr.d_spill; p.spill_stride = FUSED_CCAP;
+    p.spill = (uint2 *)spill_ptr; p.spill_stride = ccap;
     { const char *dv = getenv("HX_F_DBG"); p.fdbg = dv ? (uint32_t)atoi(dv) : 0u; }
-    p.vis = mr.d_vis; p.vis_words = vis_words;
+    p.vis = vis_ptr ? vis_ptr : mr.d_vis; p.vis_words = vis_words;
     p.next_task = (uint32_t *)(mr.d_io + o_ctr);
     p.n_dist = (unsigned long long *)(mr.d_io + o_ctr + 8);
     p.out_ids = (uint32_t *)(mr.d_io + o_ids); p.out_d = (float *)(mr.d_io + o_d); p.out_cnt = (uint32_t *)(mr.d_io + o_cnt);
@@ -1752,6 +1762,10 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, (mode == 2 ? o : o_tix) - o_st, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
+    if (roomy == 1 && mode != 2) {   // test hook: pretend every k-th task overflowed, so that the roomy retry path is exercised
+        const char *fv = getenv("HX_FORCE_OVERFLOW_MOD"); const uint32_t k = fv ? (uint32_t)atoi(fv) : 0u;
+        if (k) for (uint32_t t = 0; t < ntasks; t += k) ((uint32_t *)(mr.h_io + o_st))[t] = FS_OVERFLOW;
+    }
     if (view) {   // the caller reads the pinned staging buffer in place
         view->status = (const uint32_t *)(mr.h_io + o_st); view->cnt = (const uint32_t *)(mr.h_io + o_cnt);
         view->ids = (const uint32_t *)(mr.h_io + o_ids); view->d = (const float *)(mr.h_io + o_d);

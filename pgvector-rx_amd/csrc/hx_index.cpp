@@ -818,7 +818,29 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
                 bs.searched[lo + i] = 1;
             }
         });
-        for (uint32_t i = 0; i < n; i++) { if (status[i] != 0) todo.push_back(lo + i); else ix->mark_dirty(bs.base + lo + i); }
+        std::vector<uint32_t> again;                             // members whose tables overflowed: one more try on the device with roomier tables
+        for (uint32_t i = 0; i < n; i++) { if (status[i] == 0) ix->mark_dirty(bs.base + lo + i); else if (status[i] == 1) again.push_back(lo + i); else todo.push_back(lo + i); }
+        if (!again.empty()) {
+            const uint32_t na = (uint32_t)again.size();
+            std::vector<uint32_t> q2(na); std::vector<int32_t> l2(na);
+            for (uint32_t k = 0; k < na; k++) { q2[k] = bs.base + again[k]; l2[k] = g.level[bs.base + again[k]]; }
+            HxFusedView v2;
+            if ((rc = ix->e->fused_run(1, na, q2.data(), l2.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
+                                       nullptr, nullptr, nullptr, nullptr, cnts, nullptr, &v2, 8))) return ix->fail(rc, ix->e->err);
+            ix->counters[1] += cnts[0]; ix->counters[2] += cnts[1];
+            for (uint32_t k = 0; k < na; k++) {
+                const uint32_t id = bs.base + again[k];
+                if (v2.status[k] != 0) { todo.push_back(again[k]); continue; }
+                for (int lc = 0; lc <= g.level[id]; lc++) {
+                    const uint32_t c = v2.cnt[(size_t)k * HX_FUSED_MAXL + lc]; Cand *lst = g.list(id, lc);
+                    const size_t ob = ((size_t)k * HX_FUSED_MAXL + lc) * lm0;
+                    for (uint32_t j = 0; j < c; j++) lst[j] = Cand{v2.d[ob + j], v2.ids[ob + j]};
+                    g.cnt(id, lc) = (uint16_t)c;
+                }
+                ix->mark_dirty(id);
+                bs.searched[again[k]] = 1;
+            }
+        }
         ix->fused_tasks += n; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
     } else {
@@ -1265,7 +1287,32 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
                 counts_out[q] = c;
             }
         });
-        for (uint32_t q = 0; q < nq; q++) if (status[q] != 0) todo.push_back(q);
+        std::vector<uint32_t> again;                             // overflowed queries: one more try on the device with roomier tables
+        for (uint32_t q = 0; q < nq; q++) { if (status[q] == 1) again.push_back(q); else if (status[q] != 0) todo.push_back(q); }
+        if (!again.empty()) {
+            const uint32_t na = (uint32_t)again.size();
+            std::vector<uint32_t> q2(na);
+            for (uint32_t k = 0; k < na; k++) q2[k] = HX_QUERY_SLOT | again[k];
+            HxFusedView v2;
+            if ((rc = ix->e->fused_run(0, na, q2.data(), nullptr, ef_search, ke, (uint32_t)g.entry, g.level[g.entry],
+                                       nullptr, nullptr, nullptr, nullptr, cnts, nullptr, &v2, 8))) return ix->fail(rc, ix->e->err);
+            ix->counters[4] += cnts[0];
+            for (uint32_t k = 0; k < na; k++) {
+                const uint32_t q = again[k];
+                if (v2.status[k] != 0) { todo.push_back(q); continue; }
+                uint32_t c = 0;
+                for (uint32_t i = 0; i < v2.cnt[k] && c < limit; i++) {
+                    const uint32_t el = v2.ids[(size_t)k * ke + i];
+                    for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
+                        tids_out[(size_t)q * limit + c] = g.tids[el][t];
+                        if (dist_out) dist_out[(size_t)q * limit + c] = v2.d[(size_t)k * ke + i];
+                        if (elems_out) elems_out[(size_t)q * limit + c] = el;
+                        c++;
+                    }
+                }
+                counts_out[q] = c;
+            }
+        }
         ix->fused_tasks += nq; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
     } else if (mode != 0 && ix->fused_ok() && ix->g.entry >= 0 && limit <= 4096) {

@@ -46,6 +46,7 @@ struct HxMirror {
     float *d_pm = nullptr; uint8_t *d_pm_valid = nullptr; uint64_t cap_pm = 0;   // resident pair matrices of the layer-0 lists
     uint32_t *d_vis = nullptr; uint64_t cap_vis = 0;
     void *d_spill = nullptr;                 // candidate-heap spill areas of the fused kernel's workgroups
+    void *d_spill_big = nullptr; size_t cap_spill_big = 0; uint32_t *d_vis_big = nullptr; uint64_t cap_vis_big = 0;   // tables of a retry launch (fused_run roomy > 1)
     void *d_disc = nullptr; size_t cap_disc = 0;             // `discarded` heaps of iterative scans (k_fused MODE 2)
     uint16_t *d_emask = nullptr; uint64_t cap_emask = 0;     // per-element heap-TID filter masks of the current iterative scan
     uint8_t *h_stage = nullptr, *d_stage = nullptr; size_t cap_stage = 0;
@@ -94,7 +95,7 @@ struct hx_engine {
                   bool want_lists = true);   // false: the updated lists stay in the mirror only (the host pulls them when it needs them)
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                  uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr);
+                  uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr, uint32_t roomy = 1);   // roomy > 1: retry of overflowed tasks with that many times the visited table and candidate heap
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 

@@ -589,3 +589,29 @@ def test_randomized_shapes_match_oracle(case):
         assert it[0][q, :it[2][q]].tolist() == wit
     ix.close()
     e.close()
+
+
+@pytest.mark.gpu
+def test_overflowed_tasks_are_retried_on_the_device_with_roomier_tables():
+    """A task whose visited table or candidate heap overflows is re-run by k_fused with 8x the tables before the lock-step path
+    is considered (it would need the host copy of every list).  HX_FORCE_OVERFLOW_MOD marks every 3rd task as overflowed."""
+    import os
+    rng = np.random.default_rng(77)
+    n, dim, m, efc = 1500, 20, 8, 40
+    rows = make_rows(hx.F32, n, dim, rng)
+    levels = hx.draw_levels(n, m, seed=77)
+    os.environ["HX_FORCE_OVERFLOW_MOD"] = "3"
+    try:
+        e, ix, _, o, _ = build_both(hx.F32, hx.L2SQ, dim, rows, levels, m, efc, 128)
+        assert ix.fused_stats()["redone"] == 0                       # nothing reached the lock-step path
+        assert_same_graph(ix, o, n)
+        qs = make_rows(hx.F32, 30, dim, rng)
+        e.set_queries(qs)
+        tids, d, el, cnt = ix.search(30, 24, 7)
+        for q in range(30):
+            assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=24, limit=7)]
+        assert ix.fused_stats()["redone"] == 0
+    finally:
+        del os.environ["HX_FORCE_OVERFLOW_MOD"]
+    ix.close()
+    e.close()
