@@ -104,7 +104,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            try:   # RCCL over xGMI; a rendezvous / first-collective failure falls back to gloo (host tensors) so the run still measures
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as ex:   # noqa: BLE001
+                print("bench.py: nccl backend unavailable (%s); using gloo" % (str(ex).splitlines()[0] if str(ex) else type(ex).__name__), file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:   # noqa: BLE001
+                    pass
+                a.dist_backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
