@@ -1250,9 +1250,11 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
         r = __shfl(r, 0, 64);
         F_WSYNC();
         LC_TICK(2);
-        if (SPEC) {   // unchanged iff the new row is the one left out AND the survivors keep their slots, in order
+        {   // unchanged iff the new row is the one left out AND the survivors keep their slots, in order: nothing to rebuild then
             const bool ok = lane >= r || pos[sel[lane]] == lane;
-            return __ballot(!ok) != 0ull;
+            const bool changed = __ballot(!ok) != 0ull;
+            if (SPEC) return changed;
+            if (!changed) { LC_TICK(4); return true; }            // (a pruned list stays in select order: still "pruned" for the caller)
         }
         {   // the new row's distances to every slot are needed only if it stays in the list
             bool mine = lane < r && pos[sel[lane]] == LC_SLOTS;
