@@ -104,7 +104,13 @@ def run(name, n, data="baseline"):
     if normalize:
         norms = eng.normalize_rows(0, n)
         skipped = int((norms == 0).sum())
-        rown = torch.from_numpy(eng.read_rows(0, n)).to(DEV) if n <= 200_000 else torch.nn.functional.normalize(rows.double(), dim=1).float()
+        if n <= 200_000:
+            rown = torch.from_numpy(eng.read_rows(0, n)).to(DEV)
+        else:                       # in place, chunk by chunk (at the full C3 size a second copy would not fit next to the engine's)
+            for i in range(0, n, 1 << 18):
+                j = min(n, i + (1 << 18))
+                rows[i:j] = torch.nn.functional.normalize(rows[i:j].double(), dim=1).float()
+            rown = rows
         gt_fn = lambda: topk_chunks(lambda a, b: qs[a:b] @ rown.T, nq, n, k, True)
     levels = hx.draw_levels(n, m, seed=21)
     ix = hx.Index(eng, m, efc)
