@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("HX_LIB") or os.path.join(HERE, "libhnswrx.so")   # HX_LIB: load a prebuilt variant as is (kernel tuning experiments)
-SOURCES = ["hx_engine.hip", "hx_index.cpp"]
+SOURCES = ["hx_engine.hip", "hx_group.hip", "hx_index.cpp"]
 HEADERS = ["hx_internal.h", os.path.join("..", "..", "include", "hnswrx.h")]
 # -ffp-contract=off: mul and add are rounded separately, as in the reference's unfused Rust
 # (and as the oracle's ORC_ORDER_W64 emulation assumes).

@@ -1114,7 +1114,7 @@ k_links(const LinksParams p)
     }
     if (threadIdx.x < cnt) {
         gl_ids[threadIdx.x] = lid[threadIdx.x]; gl_d[threadIdx.x] = ld[threadIdx.x];
-        p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x];
+        if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x]; }
     }
     if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, pairs); }
 }
@@ -1317,14 +1317,14 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
         (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr);
     if (lane < cnt) {
         gl_ids[lane] = lid[lane]; gl_d[lane] = ld[lane];
-        p.out_ids[(size_t)g * 2u * p.m + lane] = lid[lane]; p.out_d[(size_t)g * 2u * p.m + lane] = ld[lane];
+        if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + lane] = lid[lane]; p.out_d[(size_t)g * 2u * p.m + lane] = ld[lane]; }
     }
     if (cached) {
         float *dst = pm + (size_t)target * LC_TRI;
         for (uint32_t i = lane; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64) dst[i] = M[i];
         if (lane == 0) pm_valid[target] = (uint8_t)v;
     }
-    if (lane == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
+    if (lane == 0) { *gl_cnt = (uint16_t)cnt; if (p.out_cnt) p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
     if (tm && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk[5] = __builtin_amdgcn_s_memtime() - tk0; for (int i = 0; i < 6; i++) atomicAdd(p.n_pairs + 1 + i, tk[i]); }
 }
 
@@ -1405,14 +1405,14 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
     cnt = ctl[1]; v = ctl[2];
     if (threadIdx.x < cnt) {
         gl_ids[threadIdx.x] = lid[threadIdx.x]; gl_d[threadIdx.x] = ld[threadIdx.x];
-        p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x];
+        if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x]; }
     }
     if (cached) {
         float *dst = pm + (size_t)target * LC_TRI;
         for (uint32_t i = threadIdx.x; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64 * HUB_W) dst[i] = M[i];
         if (threadIdx.x == 0) pm_valid[target] = (uint8_t)v;
     }
-    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; }
+    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; if (p.out_cnt) p.out_cnt[g] = cnt; }
     if (lane == 0) atomicAdd(p.n_pairs, ndist);
 }
 
@@ -1578,6 +1578,79 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     *out_cnt = (const uint32_t *)(h + o_cnt); *out_ids = (const uint32_t *)(h + o_ids); *out_d = (const float *)(h + o_d);
     unsigned long long np; memcpy(&np, h + o_ctr, 8);
     if (p.dbg & 8u) { unsigned long long t[7]; memcpy(t, h + o_ctr, 56); fprintf(stderr, "[hx] k_links_cached groups %u ops %u: ticks matrix-fill %llu sort %llu walk %llu lazy-nd %llu rebuild %llu; whole kernel per wave %llu\n", n_groups, n_ops, t[1], t[2], t[3], t[4], t[5], t[6]); }
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    return HX_OK;
+}
+
+int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys, const uint32_t *op_new, const float *op_d, uint64_t *n_pairs, uint32_t stats[2])
+{
+    HxMirror &mr = mirror;
+    stats[0] = stats[1] = 0;
+    if (n_pairs) *n_pairs = 0;
+    if (n_ops == 0) return HX_OK;
+    if (2 * mr.m != LC_SLOTS || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "device-side op grouping serves m = 16 and rows <= 8 KiB");
+    HX_HIP(this, hipSetDevice(device));
+    if (mr.cap_pm < mr.cap) {                                   // pair-matrix cache for every layer-0 list (as in links_run)
+        float *npm = nullptr; uint8_t *nv = nullptr;
+        HX_HIP(this, hipMalloc((void **)&npm, (size_t)mr.cap * LC_TRI * sizeof(float)));
+        HX_HIP(this, hipMalloc((void **)&nv, mr.cap));
+        HX_HIP(this, hipMemsetAsync(nv, 0, mr.cap, stream));
+        if (mr.d_pm && mr.cap_pm) {
+            HX_HIP(this, hipMemcpyAsync(npm, mr.d_pm, (size_t)mr.cap_pm * LC_TRI * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HX_HIP(this, hipMemcpyAsync(nv, mr.d_pm_valid, mr.cap_pm, hipMemcpyDeviceToDevice, stream));
+        }
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (mr.d_pm) (void)hipFree(mr.d_pm);
+        if (mr.d_pm_valid) (void)hipFree(mr.d_pm_valid);
+        mr.d_pm = npm; mr.d_pm_valid = nv; mr.cap_pm = mr.cap;
+    }
+    if (mr.cap_lk < 256) {                                      // counters live in the links staging buffers
+        if (mr.h_lk) (void)hipHostFree(mr.h_lk);
+        if (mr.d_lk) (void)hipFree(mr.d_lk);
+        mr.h_lk = mr.d_lk = nullptr; mr.cap_lk = 0;
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_lk, 4096, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&mr.d_lk, 4096));
+        mr.cap_lk = 4096;
+    }
+    static const uint32_t hub_min = getenv("HX_HUB_MIN") ? (uint32_t)atoi(getenv("HX_HUB_MIN")) : 48u;
+    uint32_t c[4];
+    int rc = hx_group_ops(this, n_ops, keys, op_new, op_d, hub_min, grp, c);
+    if (rc) return rc;
+    const uint32_t n_groups = c[0], n_hub = c[1], n_norm = c[2];
+    stats[0] = n_groups; stats[1] = c[3];
+    LinksParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.m = mr.m;
+    p.l0_ids = mr.d_l0_ids; p.l0_d = mr.d_l0_d; p.l0_cnt = mr.d_l0_cnt; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_d = mr.d_up_d; p.up_cnt = mr.d_up_cnt;
+    p.n_groups = n_groups; p.target = grp.tg; p.layer = grp.ly; p.op_off = grp.off; p.op_new = grp.op_new; p.op_d = grp.op_d; p.gmap = nullptr;
+    p.out_ids = nullptr; p.out_d = nullptr; p.out_cnt = nullptr;
+    p.n_pairs = (unsigned long long *)mr.d_lk;
+    { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
+    HX_HIP(this, hipMemsetAsync(mr.d_lk, 0, 64, stream));
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+    if (n_hub) {
+        LinksParams ph = p; ph.n_groups = n_hub; ph.gmap = grp.gmap_hub;
+#define F32C(K) ls = launch_links_hub<OpF32<K>>(this, ph)
+#define F16C(K) ls = launch_links_hub<OpF16<K>>(this, ph)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links_hub<OpHamming>(this, ph), ls = launch_links_hub<OpJaccard>(this, ph));
+#undef F32C
+#undef F16C
+        HX_HIP(this, ls);
+    }
+    if (n_norm) {
+        p.n_groups = n_norm; p.gmap = grp.gmap_norm;
+#define F32C(K) ls = launch_links_cached<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_links_cached<OpF16<K>>(this, p)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links_cached<OpHamming>(this, p), ls = launch_links_cached<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+        HX_HIP(this, ls);
+    }
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk, mr.d_lk, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    unsigned long long np; memcpy(&np, mr.h_lk, 8);
     if (n_pairs) *n_pairs = np;
     if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
     return HX_OK;

@@ -614,6 +614,7 @@ struct hx_index {
     bool host_stale = false, in_insert = false;
     // scratch of hx_index_batch_links, kept between batches (a batch allocates and page-faults ~10 MB otherwise)
     struct LinkScratch { std::vector<BackOp> raw; std::vector<uint32_t> hist, own, tg, ly, off, onew, opstart, da, db, dstart; std::vector<float> od; std::vector<uint8_t> deq;
+                         std::vector<unsigned long long> keys;
                          std::vector<std::vector<std::pair<size_t, size_t>>> bgrp; } ls;
     int ensure_host_lists()
     {
@@ -953,6 +954,39 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
             bs.elem[i] = id;
         }
         opstart[i + 1] = opstart[i] + nops;
+    }
+    // Single-process build on the device path: the ops are only listed here (update_neighbor_connections order, mod.rs:451-458);
+    // grouping them per (target, layer) list, hub split and the prunes all happen on the device (hx_group.hip), and the
+    // updated lists stay in the mirror until the host needs them.
+    static const bool device_grouping = !(getenv("HX_DEVICE_GROUPING") && atoi(getenv("HX_DEVICE_GROUPING")) == 0);
+    if (device_grouping && bs.lazy_lists && world == 1 && ix->fused_ok() && g.m == 16 && ix->e->pitch <= 8192) {
+        const uint32_t n_ops = opstart[b];
+        unsigned long long *keys = nullptr; uint32_t *onew = nullptr; float *od = nullptr;   // pinned staging; key = target << 7 | layer (levels reach 82 at m = 16)
+        if ((rc = ix->e->links_stage_ops(n_ops, &keys, &onew, &od))) return ix->fail(rc, ix->e->err);
+        const uint32_t csz = 128, nck = (b + csz - 1) / csz;
+        ix->pool->parallel_for(nck, [&](size_t ci) {
+            for (uint32_t i = (uint32_t)ci * csz; i < std::min(b, (uint32_t)(ci + 1) * csz); i++) {
+                const uint32_t id = base + i; uint32_t o = opstart[i];
+                if (opstart[i + 1] == o) continue;
+                for (int lc = g.level[id]; lc >= 0; lc--) {
+                    const Cand *lst = g.list(id, lc);
+                    for (uint16_t k = 0; k < g.cnt(id, lc); k++) { keys[o] = ((unsigned long long)lst[k].id << 7) | (unsigned long long)lc; onew[o] = id; od[o] = lst[k].d; o++; }
+                }
+            }
+        });
+        if ((rc = ix->sync_mirror())) return rc;
+        ix->prof[8] += hx_index::now_s() - t_links0;
+        {
+            hx_index::Timer tl(ix->prof[9]);
+            uint64_t np = 0; uint32_t st[2] = {0, 0};
+            if ((rc = ix->e->links_run_grouped(n_ops, keys, onew, od, &np, st))) return ix->fail(rc, ix->e->err);
+            ix->counters[3] += np;
+            ix->prof[13] = std::max(ix->prof[13], (double)st[1]); ix->prof[14] += n_ops;
+            if (n_ops) ix->host_stale = true;
+        }
+        bs.ops.clear(); bs.grp.clear();
+        bs.linked = true;
+        return HX_OK;
     }
     // Back-link ops in update_neighbor_connections order (mod.rs:451-458), then grouped per (target, layer) with the
     // insertion order kept inside a group: parallel stable bucket sort (bucket = target & 255; buckets are independent).

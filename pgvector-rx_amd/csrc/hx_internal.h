@@ -56,6 +56,16 @@ struct HxMirror {
 // zero-copy view of a fused_run's results in the engine's pinned staging buffer (valid until the next fused_run)
 struct HxFusedView { const uint32_t *ids = nullptr, *cnt = nullptr, *status = nullptr; const float *d = nullptr; };
 
+// device-side grouping of a batch's back-link ops (hx_group.hip): workspace + the grouped arrays it leaves on the device
+struct HxGroupWork {
+    uint8_t *d = nullptr; size_t cap = 0; uint32_t *h_ctr = nullptr; uint8_t *h = nullptr; size_t cap_h = 0;   // device workspace, pinned counters, pinned op staging
+    const uint32_t *tg = nullptr, *ly = nullptr, *off = nullptr, *op_new = nullptr, *gmap_hub = nullptr, *gmap_norm = nullptr; const float *op_d = nullptr;
+};
+struct hx_engine;
+int hx_group_stage(hx_engine *e, uint32_t n_ops, HxGroupWork &w, unsigned long long **keys, uint32_t **op_new, float **op_d);
+int hx_group_ops(hx_engine *e, uint32_t n_ops, const unsigned long long *h_keys, const uint32_t *h_new, const float *h_d, uint32_t hub_min,
+                 HxGroupWork &w, uint32_t counters_out[4]);   // counters: groups, hub lists, other lists, longest chain
+
 // arguments of an iterative scan on the device (k_fused MODE 2)
 struct HxFusedIter {
     int iter_mode = 1; long long max_tuples = 0;       // 1 relaxed_order, 2 strict_order; hnsw.max_scan_tuples
@@ -90,6 +100,11 @@ struct hx_engine {
     // back to the mirror, and returned: out_cnt[g], out_ids/out_d [g][2m]
     // copies the mirror's lists of elements [0, n_elems) / upper-layer blocks [0, n_blocks) to host arrays (ids and distances SoA, counts)
     int mirror_download(uint64_t n_elems, uint64_t n_blocks, uint32_t *l0_ids, float *l0_d, uint16_t *l0_cnt, uint32_t *up_ids, float *up_d, uint16_t *up_cnt);
+    // update_neighbor_connections for a batch whose ops (key = target << 7 | layer, new element, distance; op order) are grouped on the device;
+    // the updated lists stay in the mirror.  stats: [0] groups, [1] longest chain
+    int links_stage_ops(uint32_t n_ops, unsigned long long **keys, uint32_t **op_new, float **op_d) { return hx_group_stage(this, n_ops, grp, keys, op_new, op_d); }
+    int links_run_grouped(uint32_t n_ops, const unsigned long long *keys, const uint32_t *op_new, const float *op_d, uint64_t *n_pairs, uint32_t stats[2]);
+    HxGroupWork grp;
     int links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
                   const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs,
                   bool want_lists = true);   // false: the updated lists stay in the mirror only (the host pulls them when it needs them)
