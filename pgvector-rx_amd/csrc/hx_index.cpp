@@ -1291,8 +1291,10 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
     if (nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
     std::vector<uint32_t> todo;                                  // query slots for the lock-step path
     if (mode == 0 && ix->fused_ok() && ix->g.entry >= 0) {
+        const double t_sm0 = hx_index::now_s();
         int rc = ix->sync_mirror();
         if (rc) return rc;
+        ix->prof[4] += hx_index::now_s() - t_sm0;
         const Graph &g = ix->g;
         const uint32_t ke = std::min<uint32_t>(limit, ef_search);
         std::vector<uint32_t> qsel(nq);
@@ -1305,9 +1307,13 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
         ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ix->counters[4] += cnts[0];
         const uint32_t *status = v.status, *ocnt = v.cnt, *oids = v.ids; const float *od = v.d;
+        const double t_exp0 = hx_index::now_s();
         ix->pool->parallel_for((nq + 1023) / 1024, [&](size_t ci) {
             for (uint32_t q = (uint32_t)ci * 1024; q < std::min<uint32_t>(nq, (uint32_t)ci * 1024 + 1024); q++) {
                 if (status[q] != 0) continue;
+                if (q + 1 < nq) for (uint32_t i = 0; i < ocnt[q + 1] && i < ke; i++) {      // the heap TIDs of the next query's elements: random host reads
+                    const uint32_t eln = oids[(size_t)(q + 1) * ke + i]; __builtin_prefetch(&g.tids[eln]); __builtin_prefetch(&g.ntids[eln]);
+                }
                 uint32_t c = 0;                                  // amgettuple: every heap TID of each element, nearest first (scan.rs:794-875)
                 for (uint32_t i = 0; i < ocnt[q] && c < limit; i++) {
                     const uint32_t el = oids[(size_t)q * ke + i];
@@ -1321,6 +1327,7 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
                 counts_out[q] = c;
             }
         });
+        ix->prof[15] += hx_index::now_s() - t_exp0;
         std::vector<uint32_t> again;                             // overflowed queries: one more try on the device with roomier tables
         for (uint32_t q = 0; q < nq; q++) { if (status[q] == 1) again.push_back(q); else if (status[q] != 0) todo.push_back(q); }
         if (!again.empty()) {
