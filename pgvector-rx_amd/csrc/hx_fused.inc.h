@@ -1738,7 +1738,11 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
     { const char *pv = getenv(mode == 0 ? "HX_QUERY_PER_CU" : "HX_INSERT_PER_CU"); if (mode != 2 && pv && atoi(pv) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(pv)); }   // tuning knob
     uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
-    uint64_t vis_words = 4096; while (vis_words < (uint64_t)ef * 2 * mr.m * 4 + 2048) vis_words <<= 1;   // >= 4x the ids a search touches at its usual ~ef expansions (at 10M rows some searches visit 2x that)
+    // >= 2x the ids a search touches at its usual ~ef expansions; twice that on indexes of >= 4M rows, where some searches reach further.
+    // Measured on 1M x 768: a table twice as large costs 3-6 % of the scan rate (cache footprint), one half as large overflows and retries.
+    const uint64_t vis_need = ((uint64_t)ef * 2 * mr.m * 2 + 1024) * (n_rows >= 4000000ull ? 2 : 1);
+    uint64_t vis_words = 4096; while (vis_words < vis_need) vis_words <<= 1;
+    { const char *vv = getenv("HX_VIS_SHIFT"); if (vv && mode != 2) { const int sh = atoi(vv); if (sh < 0) vis_words >>= -sh; else vis_words <<= sh; if (vis_words < 4096) vis_words = 4096; } }   // tuning knob
     vis_words *= roomy;
     uint64_t disc_stride = 0;
     if (mode == 2) {
