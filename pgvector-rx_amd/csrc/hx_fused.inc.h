@@ -1751,6 +1751,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         const uint64_t mt = (uint64_t)std::min<long long>(std::max<long long>(it->max_tuples, 1), 1 << 20);
         disc_stride = std::max<uint64_t>(4 * mt, 16384);
         while (vis_words < 8 * mt + 4096) vis_words <<= 1;
+        { const char *vv = getenv("HX_ITER_VIS_SHIFT"); if (vv) { const int sh = atoi(vv); if (sh < 0) vis_words >>= -sh; else vis_words <<= sh; if (vis_words < 8192) vis_words = 8192; } }   // tuning knob
         // at most ~12 GB of per-query state: a huge max_scan_tuples gets fewer resident queries, never less than one per CU pair
         const uint64_t per_wg = disc_stride * 8 + vis_words * 4;
         const uint32_t fit = (uint32_t)std::max<uint64_t>(128, (12ull << 30) / per_wg);
