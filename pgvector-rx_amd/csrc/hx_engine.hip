@@ -17,139 +17,9 @@
 //   lanes' partials are +0.0 and x + 0.0 == x for every accumulator value reachable here.
 //
 // There is no CPU fallback anywhere in this file: without a GPU hx_create fails with HX_E_NODEVICE.
-#include "hx_internal.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdlib>
-#include <cstring>
-
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+#include "hx_ops.h"
 
 static thread_local std::string g_create_err;
-
-// =================================================================================================
-// device helpers
-// =================================================================================================
-__device__ __forceinline__ float bits2f(unsigned int u) { return __builtin_bit_cast(float, u); }
-__device__ __forceinline__ float half2f(unsigned int h16)
-{   // exact widening, subnormals included (half_to_f32, halfvec.rs:54-87)
-    return (float)__builtin_bit_cast(_Float16, (unsigned short)h16);
-}
-
-// xor-butterfly exchange v[lane ^ OFF] without touching LDS: __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar round
-// trip, ~100+ cycles each, six in a row per reduced value -- measured as half of a row batch's time in the traversal
-// kernel).  gfx950 has the half/row swaps as VALU ops, and the steps inside a 16-lane row are DPP moves:
-//   32: v_permlane32_swap(v, v) leaves {lo,lo} and {hi,hi}; 16: v_permlane16_swap likewise on row pairs;
-//   8 = row_half_mirror . row_mirror, 4 = quad_perm[3,2,1,0] . row_half_mirror, 2 / 1 = quad_perm.
-// The sums are the butterfly's own (a + b is the same value in both partners), so the canonical order is unchanged.
-template <int CTRL> __device__ __forceinline__ unsigned int dpp_mov(unsigned int v)
-{
-    return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-}
-template <int OFF> __device__ __forceinline__ void xor_pair(unsigned int v, unsigned int &a, unsigned int &b)
-{   // a (+) b == v[lane] (+) v[lane ^ OFF] for a commutative (+)
-    if constexpr (OFF == 32) { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); a = r[0]; b = r[1]; }
-    else if constexpr (OFF == 16) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); a = r[0]; b = r[1]; }
-    else if constexpr (OFF == 8) { a = v; b = dpp_mov<0x141>(dpp_mov<0x140>(v)); }
-    else if constexpr (OFF == 4) { a = v; b = dpp_mov<0x1B>(dpp_mov<0x141>(v)); }
-    else if constexpr (OFF == 2) { a = v; b = dpp_mov<0x4E>(v); }
-    else { a = v; b = dpp_mov<0xB1>(v); }
-}
-template <int LPR, int OFF> __device__ __forceinline__ float lanes_sum_f_step(float v)
-{
-    if constexpr (OFF < LPR) {
-        unsigned int a, b; xor_pair<OFF>(__builtin_bit_cast(unsigned int, v), a, b);
-        v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
-    }
-    if constexpr (OFF > 1) return lanes_sum_f_step<LPR, OFF / 2>(v); else return v;
-}
-template <int LPR, int OFF> __device__ __forceinline__ int lanes_sum_i_step(int v)
-{
-    if constexpr (OFF < LPR) { unsigned int a, b; xor_pair<OFF>((unsigned int)v, a, b); v = (int)a + (int)b; }
-    if constexpr (OFF > 1) return lanes_sum_i_step<LPR, OFF / 2>(v); else return v;
-}
-template <int LPR> __device__ __forceinline__ float lanes_sum_f(float v) { return lanes_sum_f_step<LPR, 32>(v); }
-template <int LPR> __device__ __forceinline__ int lanes_sum_i(int v) { return lanes_sum_i_step<LPR, 32>(v); }
-
-// ---- per-(dtype, metric) operators: add() consumes one 16-byte fragment pair, finish() reduces ----
-enum { K_L2 = 0, K_IP = 1, K_L1 = 2 };
-
-template <int KIND> __device__ __forceinline__ void fterm(float &acc, float x, float y)
-{
-    if (KIND == K_L2) { float d = x - y; acc = acc + d * d; }
-    else if (KIND == K_IP) { acc = acc + x * y; }
-    else { acc = acc + __builtin_fabsf(x - y); }
-}
-
-template <int KIND> struct OpF32 {
-    typedef float acc_t;
-    static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
-    static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)
-    {
-#pragma unroll
-        for (int t = 0; t < 4; t++) fterm<KIND>(acc, bits2f(a[t]), bits2f(b[t]));
-    }
-    template <int LPR> static __device__ __forceinline__ float finish(acc_t acc)
-    {
-        float s = lanes_sum_f<LPR>(acc);
-        return KIND == K_IP ? -s : s;      // vector_negative_inner_product, vector.rs:631
-    }
-    static constexpr bool kFloatAcc = true;
-    static __device__ __forceinline__ float post(float s) { return KIND == K_IP ? -s : s; }
-};
-
-template <int KIND> struct OpF16 {
-    typedef float acc_t;
-    static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
-    static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)
-    {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            fterm<KIND>(acc, half2f(a[t] & 0xffffu), half2f(b[t] & 0xffffu));
-            fterm<KIND>(acc, half2f(a[t] >> 16), half2f(b[t] >> 16));
-        }
-    }
-    template <int LPR> static __device__ __forceinline__ float finish(acc_t acc)
-    {
-        float s = lanes_sum_f<LPR>(acc);
-        return KIND == K_IP ? -s : s;
-    }
-    static constexpr bool kFloatAcc = true;
-    static __device__ __forceinline__ float post(float s) { return KIND == K_IP ? -s : s; }
-};
-
-struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
-    typedef int acc_t;
-    static __device__ __forceinline__ void init(acc_t &a) { a = 0; }
-    static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)
-    {
-#pragma unroll
-        for (int t = 0; t < 4; t++) acc += __popc(a[t] ^ b[t]);
-    }
-    template <int LPR> static __device__ __forceinline__ float finish(acc_t acc) { return (float)lanes_sum_i<LPR>(acc); }
-    static constexpr bool kFloatAcc = false;
-    static __device__ __forceinline__ float post(float s) { return s; }
-};
-
-struct JacAcc { int ab, aa, bb; };
-struct OpJaccard {   // bitvec.rs:113-132
-    typedef JacAcc acc_t;
-    static __device__ __forceinline__ void init(acc_t &a) { a.ab = a.aa = a.bb = 0; }
-    static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)
-    {
-#pragma unroll
-        for (int t = 0; t < 4; t++) { acc.ab += __popc(a[t] & b[t]); acc.aa += __popc(a[t]); acc.bb += __popc(b[t]); }
-    }
-    template <int LPR> static __device__ __forceinline__ float finish(acc_t acc)
-    {
-        int ab = lanes_sum_i<LPR>(acc.ab), aa = lanes_sum_i<LPR>(acc.aa), bb = lanes_sum_i<LPR>(acc.bb);
-        double d = ab == 0 ? 1.0 : 1.0 - ((double)ab / (double)(aa + bb - ab));
-        return (float)d;                   // f64 result, `as f32` on the build path (build.rs:367)
-    }
-    static constexpr bool kFloatAcc = false;
-    static __device__ __forceinline__ float post(float s) { return s; }
-};
 
 // =================================================================================================
 // K1: query-vs-rows, one workgroup per expansion group.
@@ -208,48 +78,6 @@ k_dist_groups(const uint8_t *__restrict__ rows, const uint8_t *__restrict__ quer
     }
 }
 
-// 64 butterflies at once: a[s] is this lane's partial of pair s (s < 64).  Stage k exchanges half of the live values
-// across lanes l <-> l^off and adds, halving the number of live registers; every add has exactly the two operands the
-// plain xor butterfly of that pair has at that stage (p[l] + p[l^off], commutative), so the sums are the same bits.
-// Returns, in lane l, the full sum of pair l.  63 cross-lane moves instead of 64*6.
-template <int N> __device__ __forceinline__ void xstage(const float (&in)[2 * N], float (&out)[N], uint32_t lane, int off)
-{
-    const bool up = (lane & (uint32_t)off) != 0;
-#pragma unroll
-    for (int s = 0; s < N; s++) {
-        const float lo = in[s], hi = in[s + N];
-        const float send = up ? lo : hi, keep = up ? hi : lo;
-        out[s] = keep + __shfl_xor(send, off, 64);
-    }
-}
-__device__ __forceinline__ float reduce64_transposed(const float (&a)[64], uint32_t lane)
-{
-    float v32[32], v16[16], v8[8], v4[4], v2[2], v1[1];
-    xstage<32>(a, v32, lane, 32); xstage<16>(v32, v16, lane, 16); xstage<8>(v16, v8, lane, 8);
-    xstage<4>(v8, v4, lane, 4); xstage<2>(v4, v2, lane, 2); xstage<1>(v2, v1, lane, 1);
-    return v1[0];
-}
-// results of a wave's HX_PAIRS_PER_WAVE accumulators: res0 = pair `lane` (< 64), res1 = pair 64+lane (lanes 0,1)
-template <class OP, int NP>
-__device__ __forceinline__ void reduce_pairs(typename OP::acc_t (&acc)[NP], uint32_t lane, float &res0, float &res1)
-{
-    res0 = 0.0f; res1 = 0.0f;
-    if constexpr (OP::kFloatAcc && NP >= 64) {
-        float a[64];
-#pragma unroll
-        for (int s = 0; s < 64; s++) a[s] = acc[s];
-        res0 = OP::post(reduce64_transposed(a, lane));
-#pragma unroll
-        for (int s = 64; s < NP; s++) { const float d = OP::template finish<64>(acc[s]); if (lane == (uint32_t)(s - 64)) res1 = d; }
-    } else {
-#pragma unroll
-        for (int s = 0; s < NP; s++) {
-            const float d = OP::template finish<64>(acc[s]);
-            if (s < 64) { if (lane == (uint32_t)s) res0 = d; } else { if (lane == (uint32_t)(s - 64)) res1 = d; }
-        }
-    }
-}
-
 // =================================================================================================
 // K2: many small pair blocks (select_neighbors / back-link pruning operands).
 //   One 512-thread workgroup per slab of <= HX_PAIR_SLAB pairs of one group (a 33-row back-link block is
@@ -261,19 +89,6 @@ __device__ __forceinline__ void reduce_pairs(typename OP::acc_t (&acc)[NP], uint
 //   Same canonical order as K1, so d(a,b) is the same bits whichever kernel produced it.
 //   LDS/VALU-bound, not HBM-bound: each row is fetched once per slab and reused for up to 63 pairs.
 // =================================================================================================
-#define HX_PAIR_WG 512
-#define HX_PAIR_WAVES 8
-#define HX_PAIRS_PER_WAVE 66
-#define HX_PAIR_SLAB (HX_PAIR_WAVES * HX_PAIRS_PER_WAVE)   /* 528 = 33*32/2 */
-
-__device__ __forceinline__ void tri_decode(uint32_t p, uint32_t &i, uint32_t &j)
-{   // p = i*(i-1)/2 + j, j < i
-    uint32_t ii = (uint32_t)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-    while (ii * (ii - 1) / 2 > p) ii--;
-    while ((ii + 1) * ii / 2 <= p) ii++;
-    i = ii; j = p - ii * (ii - 1) / 2;
-}
-
 // STAGE = rows a wave stages per chunk (>= ceil(rows of the largest group / 8)); MINW = waves per SIMD asked of
 // the register allocator (4 = two workgroups per CU).
 template <class OP, int STAGE, int MINW>
@@ -470,19 +285,6 @@ static hipError_t launch_pair(hx_engine *e, uint32_t n_wgs, uint32_t lds_rows)
     if (lds_rows <= 40) return launch_pair_v<OP, 5, 2>(e, n_wgs, lds_rows);
     return launch_pair_v<OP, 8, 2>(e, n_wgs, lds_rows);
 }
-
-#define HX_DISPATCH(e, CALL_F32, CALL_F16, CALL_HAM, CALL_JAC)                               \
-    do {                                                                                      \
-        if ((e)->dtype == HX_F32) {                                                           \
-            if ((e)->metric == HX_L2SQ) { CALL_F32(K_L2); } else if ((e)->metric == HX_NEG_IP) { CALL_F32(K_IP); } else { CALL_F32(K_L1); } \
-        } else if ((e)->dtype == HX_F16) {                                                    \
-            if ((e)->metric == HX_L2SQ) { CALL_F16(K_L2); } else if ((e)->metric == HX_NEG_IP) { CALL_F16(K_IP); } else { CALL_F16(K_L1); } \
-        } else {                                                                              \
-            if ((e)->metric == HX_HAMMING) { CALL_HAM; } else { CALL_JAC; }                   \
-        }                                                                                     \
-    } while (0)
-
-static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 int hx_engine::layout_round(const HxRound &r)
 {

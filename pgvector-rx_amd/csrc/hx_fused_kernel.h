@@ -1,0 +1,492 @@
+// hx_fused_kernel.h -- the device-resident HNSW traversal kernel (one wavefront per search) and its launchers; included by one
+// translation unit per element type (hx_fused_f32.hip / _f16.hip / _bit.hip) so that the instantiations compile in parallel.
+#pragma once
+#include "hx_fused_core.h"
+
+// Algorithm 2 with entry points EP[0..n_ep); leaves the result set in the W heap (cx.CTL[1] = |W|).
+// scan == false: search_layer (graph/mod.rs:161-255); scan == true: search_layer_disk without `discarded` (scan.rs:302-448).
+#define F_TICK(k) do { if (tm) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); cx.tph[k] += (uint32_t)(t1_ - t0); t0 = t1_; } } while (0)
+// ITER: search_layer_disk WITH the iterative scan's state (scan.rs:302-448): the visited set is the caller's and survives
+// resumes (fresh == false keeps it; eps_visited == false: resume_scan_items' entry points are already in it), and every
+// visited element that does not end in W goes to the `discarded` min-heap, in the reference's order of pushes.
+template <class OP, int LPR, bool ITER = false>
+__device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
+{
+    const uint32_t lane = cx.lane;
+    if (fresh) {   // fresh visited set
+        for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    uint32_t vcount = fresh ? 0u : cx.vcount;
+    if (eps_visited) {
+        vcount += n_ep;
+        for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(p.vis_words >> 2) - 1u, cx.EP[i].y);
+    }
+    // Pushes into `discarded` are only read back by a later resume, so they are queued (in the reference's order) and applied
+    // per expansion.  The new slots are consecutive, so at every level their ancestors form ONE contiguous index range: those
+    // ranges (< 2c + depth entries for c queued pushes) are gathered into an LDS working set with one round of loads, the c
+    // sift-ups run on the working set in queue order -- LDS latency instead of a memory hop each -- and the ranges are stored
+    // back.  Same array as pushing one by one into the heap itself.
+    uint32_t ndp = 0;
+    // queue members [j0, j0 + c) -> heap slots [dlen, dlen + c); all of them lie on the same tree level (the caller splits a
+    // queue that crosses a power of two), so "k levels up" is the same tree depth for every member and the level ranges are disjoint
+    auto d_flush_range = [&](const uint32_t j0, const uint32_t c) {
+        const uint32_t p0 = cx.dlen;
+        const uint32_t depth = 31u - (uint32_t)__builtin_clz(p0 + c);       // levels 1..depth above the new slots (1-based heap indices)
+        auto lo_of = [&](uint32_t k) { const uint32_t v = (p0 + 1u) >> k; return v ? v : 1u; };
+        auto hi_of = [&](uint32_t k) { return (p0 + c) >> k; };
+        if (lane >= 1u && lane <= depth) {                                 // per level: first index, offset of its range in the working set
+            uint32_t base = 0;
+            for (uint32_t k = 1; k < lane; k++) base += hi_of(k) - lo_of(k) + 1u;
+            cx.LV[2u * lane] = lo_of(lane); cx.LV[2u * lane + 1u] = base;
+        }
+        uint32_t total = 0;
+        for (uint32_t k = 1; k <= depth; k++) total += hi_of(k) - lo_of(k) + 1u;
+        F_WSYNC();
+        // gather: working-set slot f <-> (level, index)
+        uint32_t my_idx[2] = {0u, 0u};
+        for (int h = 0; h < 2; h++) {
+            const uint32_t f = lane + 64u * (uint32_t)h;
+            if (f < total) {
+                uint32_t k = 1, base = 0;
+                for (;; k++) { const uint32_t len = hi_of(k) - lo_of(k) + 1u; if (f < base + len) break; base += len; }
+                my_idx[h] = lo_of(k) + (f - base);
+                const uint2 v = cx.DS.ld(my_idx[h] - 1u);
+                cx.WS[f].x = v.x; cx.WS[f].y = v.y;
+            }
+        }
+        F_WSYNC();
+        for (uint32_t j = 0; j < c; j++) {                                 // the c sift-ups, in queue order, on the working set
+            const uint32_t pos1 = p0 + 1u + j;
+            const uint2 it = make_uint2(cx.DP[j0 + j].x, cx.DP[j0 + j].y);
+            const uint32_t dj = 31u - (uint32_t)__builtin_clz(pos1);
+            const bool anc = lane >= 1u && lane <= dj;
+            uint2 v = make_uint2(0u, 0u);
+            if (anc) { const uint32_t s0 = cx.LV[2u * lane + 1u] + ((pos1 >> lane) - cx.LV[2u * lane]); v = make_uint2(cx.WS[s0].x, cx.WS[s0].y); }
+            const unsigned long long sm = __ballot(anc && PHeap<true>::le(fh_d(it), fh_d(v)));
+            const uint32_t t = sm ? (uint32_t)__builtin_ctzll(sm) : dj + 1u;
+            F_WSYNC();
+            if (anc && lane < t) {                                         // ancestor `lane` moves down to the path's slot one level below
+                if (lane == 1u) { cx.DP[j0 + j].x = v.x; cx.DP[j0 + j].y = v.y; }
+                else { const uint32_t s1 = cx.LV[2u * (lane - 1u) + 1u] + ((pos1 >> (lane - 1u)) - cx.LV[2u * (lane - 1u)]); cx.WS[s1].x = v.x; cx.WS[s1].y = v.y; }
+            }
+            if (lane == 0u && t > 1u) {                                    // the new element lands at level t-1 (t == 1: it stays in its own slot, DP[j])
+                const uint32_t s1 = cx.LV[2u * (t - 1u) + 1u] + ((pos1 >> (t - 1u)) - cx.LV[2u * (t - 1u)]);
+                cx.WS[s1].x = it.x; cx.WS[s1].y = it.y;
+            }
+            F_WSYNC();
+        }
+        // store back: the ranges, then the new slots
+        for (int h = 0; h < 2; h++) {
+            const uint32_t f = lane + 64u * (uint32_t)h;
+            if (f < total) cx.DS.st(my_idx[h] - 1u, make_uint2(cx.WS[f].x, cx.WS[f].y));
+        }
+        if (lane < c) cx.DS.st(p0 + lane, make_uint2(cx.DP[j0 + lane].x, cx.DP[j0 + lane].y));
+        cx.dlen = p0 + c;
+        PHeap<true>::sync(cx.DS);
+    };
+    auto d_flush = [&]() {
+        const uint32_t c = ndp;
+        ndp = 0;
+        if (c == 0 || cx.status != FS_OK) return;
+        if (cx.dlen + c > p.disc_stride + p.disc_lds) { cx.status = FS_OVERFLOW; return; }
+        uint32_t j0 = 0;
+        while (j0 < c) {
+            if (cx.dlen < 64u) {                                           // small heap: ancestors may be queue members themselves
+                PHeap<true>::push(cx.DS, cx.dlen, make_uint2(cx.DP[j0].x, cx.DP[j0].y), lane); j0++; continue;
+            }
+            const uint32_t first1 = cx.dlen + 1u;                          // 1-based slot of the next member
+            const uint32_t level_end = (2u << (31u - (uint32_t)__builtin_clz(first1))) - 1u;   // last slot of its tree level
+            const uint32_t cs = (c - j0) < (level_end - first1 + 1u) ? (c - j0) : (level_end - first1 + 1u);
+            d_flush_range(j0, cs);
+            j0 += cs;
+        }
+    };
+    auto d_push = [&](uint2 it) {
+        if (lane == 0) { cx.DP[ndp].x = it.x; cx.DP[ndp].y = it.y; }
+        ndp++;
+        F_WSYNC();
+        if (ndp == 64u) d_flush();
+    };
+    // heaps are driven by the whole wave (PHeap) while the candidate heap fits its LDS part; a heap that outgrows it
+    // (rare) is handed to the serial hybrid LDS+spill code on lane 0.  clen/wl/rlen: |C|, |W|, result_len -- wave-uniform.
+    uint32_t clen = 0, wl = 0, rlen = 0;
+    lds_uint2 *const CA = cx.CH.lds, *const WA = cx.WH.lds;
+    auto c_push = [&](uint2 it) {
+        if (clen < cx.CH.L) PHeap<true>::push(CA, clen, it, lane);
+        else { __syncthreads(); if (lane == 0) { uint32_t l = clen; FHeap<true>::push(cx.CH, l, it); } clen++; __syncthreads(); }
+    };
+    auto c_pop = [&]() -> uint2 {
+        if (clen <= cx.CH.L) return PHeap<true>::pop(CA, clen, lane);
+        __syncthreads();
+        if (lane == 0) { uint32_t l = clen; const uint2 c = FHeap<true>::pop(cx.CH, l); cx.RES[0] = c; }
+        clen--; __syncthreads();
+        const uint2 c = cx.RES[0]; __syncthreads();
+        return c;
+    };
+    for (uint32_t i = 0; i < n_ep; i++) {
+        if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
+        const uint2 it = cx.EP[i];
+        c_push(it); PHeap<false>::push(WA, wl, it, lane);
+    }
+    rlen = wl;
+    __syncthreads();
+    for (;;) {
+        if (cx.status != FS_OK) break;
+        // pop the nearest candidate, decide whether to stop
+        const bool tm = (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+        // The candidate about to be popped is the heap's root: read it, decide, and put its neighbour list's loads in
+        // flight BEFORE the pop's heap maintenance, which then hides that memory hop.
+        uint32_t go = 0, cid = 0;
+        if (clen > 0) {
+            const uint2 c = PHeap<true>::ld(CA, 0u);
+            const float cd = fh_d(c);
+            bool stop;
+            if (!scan) { const float f = wl ? __builtin_bit_cast(float, (unsigned int)WA[0].x) : 3.402823466e+38f; stop = cd > f; }                     // mod.rs:188-193
+            else { const double f = wl ? (double)__builtin_bit_cast(float, (unsigned int)WA[0].x) : 1.7976931348623157e+308; stop = (double)cd > f; }    // scan.rs:339-346
+            if (!stop) { go = 1; cid = c.y; }
+        }
+        go = __builtin_amdgcn_readfirstlane(go); cid = __builtin_amdgcn_readfirstlane(cid);
+        const uint32_t *nb = p.l0_ids; uint32_t n = 0, lmax = 0, e_first = 0; int32_t clevel = 0x7fffffff;
+        if (go) {
+            if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; lmax = 2u * p.m; }
+            else { nb = p.up_ids + (size_t)(p.up_block[cid] + (uint32_t)(layer - 1)) * p.m; lmax = p.m; clevel = p.level[cid]; }
+            e_first = lane < lmax ? nb[lane] : 0u;                                   // issued together with the count: one memory hop
+            if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
+        }
+        uint2 popped = make_uint2(0u, 0u); const bool had = clen > 0;
+        if (had) popped = c_pop();                                                   // mod.rs:187 (the popped element is the root read above)
+        F_TICK(0);
+        if (!go) { if (ITER && had) d_push(popped); break; }                         // scan.rs:341-345 (flushed after the loop)
+        if (tm) cx.tph[7]++;
+        // a linked element at layer 0 always has level >= 0, so the check of mod.rs:198-200 needs no load there
+        if (layer > 0 && clevel < layer) continue;
+        F_TICK(1);
+        for (uint32_t n0 = 0; n0 < n; n0 += 64) {                                    // lists longer than a wave (m > 32) go in order
+            const uint32_t idx = n0 + lane;
+            uint32_t e = 0; bool unvis = false;
+            const uint32_t bmask = (uint32_t)(p.vis_words >> 2) - 1u;
+            uint32_t *vslot = nullptr; uint32_t vold = VIS_EMPTY;                    // insert in flight (settled below)
+            if (idx < n) {
+                e = n0 == 0 ? e_first : nb[idx];
+                unvis = !vis_lookup(cx.vis, bmask, e, vslot);                        // visited.contains / insert, mod.rs:206-209
+                if (unvis) vold = atomicCAS(vslot, VIS_EMPTY, e);
+                if (unvis && layer > 0 && p.level[e] < layer) unvis = false;         // mod.rs:213-216
+            }
+            F_TICK(2);
+            const unsigned long long mask = __ballot(unvis);
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            vcount += cnt;
+            if (vcount * 4u > (uint32_t)p.vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
+            if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
+            if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
+            __syncthreads();
+            F_TICK(3);
+            const float mine = f_dist_batch<OP, LPR>(p, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
+            F_TICK(4);
+            vis_settle(cx.vis, bmask, e, vslot, vold);                               // the CAS results came back with the rows
+            if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
+            cx.nd0 += cnt;
+            // Pre-filter in parallel: once W is full (result_len >= ef) its furthest distance f only shrinks while this
+            // list is replayed, so a row with d >= f NOW can never be added later in the replay; lane 0 then visits only the
+            // survivors, in list order, and re-tests each against the current f -- same pushes, same order, as mod.rs:226-243.
+            bool keep = lane < cnt;
+            if (keep && rlen >= ef && wl && !(p.fdbg & 1u)) {
+                const float f0 = __builtin_bit_cast(float, (unsigned int)WA[0].x);
+                keep = scan ? !((double)mine >= (double)f0) : (mine < f0);
+            }
+            unsigned long long km = ITER ? __ballot(lane < cnt) : __ballot(keep);     // ITER: rejected rows are visited too (they go to `discarded`)
+            F_TICK(5);
+            __syncthreads();
+            while (km) {                                                             // replay in list order, mod.rs:226-243 / scan.rs:372-429
+                const uint32_t j = (uint32_t)__builtin_ctzll(km); km &= km - 1ull;
+                const uint2 it = cx.RES[j]; const float d = fh_d(it);
+                const bool always_add = rlen < ef;
+                const float wtop = wl ? __builtin_bit_cast(float, (unsigned int)WA[0].x) : 0.0f;
+                bool add;
+                if (!scan) { const float f = wl ? wtop : 3.402823466e+38f; add = d < f || always_add; }
+                else { const double f = wl ? (double)wtop : 1.7976931348623157e+308; add = !(!always_add && (double)d >= f); }
+                if (!add) { if (ITER) { d_push(it); if (cx.status != FS_OK) break; } continue; }   // scan.rs:385-404
+                if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
+                c_push(it); PHeap<false>::push(WA, wl, it, lane); rlen++;
+                if (tm) cx.tph[8]++;
+                if (clen > cx.cmax) cx.cmax = clen;
+                if (rlen > ef) {
+                    const uint2 ev = PHeap<false>::pop(WA, wl, lane); rlen--;
+                    if (ITER) { d_push(ev); if (cx.status != FS_OK) break; }        // scan.rs:423-428
+                }
+            }
+            if (ITER) d_flush();
+            __syncthreads();
+            F_TICK(6);
+            cx.status = __shfl(cx.status, 0, 64);
+            if (cx.status != FS_OK) break;
+        }
+    }
+    if (ITER) {
+        while (clen > 0 && cx.status == FS_OK) d_push(c_pop());                      // scan.rs:432-438: what is left of C
+        d_flush();
+        cx.vcount = vcount;
+    }
+    if (lane == 0) cx.CTL[1] = wl;
+    __syncthreads();
+}
+
+// stable sort of the W heap's internal array into EP: ascending (build, mod.rs:248-254) or descending (scan.rs:441-446);
+// rank sort: ties keep their order in W's array, exactly what a stable sort of that array does
+__device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
+{
+    for (uint32_t i = cx.lane; i < n; i += 64) {
+        const uint2 me = cx.W[i]; const float d = fh_d(me);
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const float dj = fh_d(cx.W[j]);
+            rank += (desc ? dj > d : dj < d) || (dj == d && j < i);
+        }
+        cx.EP[rank] = me;
+    }
+    __syncthreads();
+}
+
+template <class OP, int MODE, int LPR>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors); LPR: lanes per row (64, or 8/32 for short rows)
+__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : FUSED_MINW))
+k_fused(const FusedParams p_in)
+{
+    FusedParams p = p_in;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    FusedCtx cx;
+    const uint32_t lm0 = 2u * p.m;
+    // LDS carve: C[ccap] | W[ef+2] | EP[ef+2] | RES[64] | RL[2m] | IDS[64] CTL[16] | QV[nch KiB].  The select phase runs
+    // after the layer's search is over, so its scratch (the candidate under test EV and the discarded list DL) reuses C.
+    cx.C = (uint2 *)lds;
+    cx.W = cx.C + p.clds;
+    cx.EP = cx.W + (p.ef + 2);
+    cx.RES = cx.EP + (p.ef + 2);
+    cx.RL = cx.RES + 64;
+    cx.IDS = (uint32_t *)(cx.RL + lm0);
+    cx.CTL = cx.IDS + 64;
+    p.dsc = (float *)(cx.CTL + 16);
+    cx.QV = (uint8_t *)(p.dsc + 64);                      // query parked in LDS (nch KiB)
+    cx.DP = (lds_uint2 *)(cx.QV + p.nch * 1024u);          // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
+    cx.WS = cx.DP + 64; cx.LV = (uint32_t *)(cx.WS + 160);   // working set of a flush (<= 2*64 + depth entries), per-level {first index, offset}
+    cx.DS.A = cx.WS + 160 + 32; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
+    cx.DS.G = MODE == 2 ? p.disc + (size_t)blockIdx.x * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
+    cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
+    cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
+    cx.CH.lds = (lds_uint2 *)cx.C; cx.CH.glob = p.spill + (size_t)blockIdx.x * p.spill_stride; cx.CH.L = p.clds;
+    cx.WH.lds = (lds_uint2 *)cx.W; cx.WH.glob = nullptr; cx.WH.L = 0xffffffffu;
+    cx.lane = threadIdx.x;
+    cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
+    cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
+    for (int i = 0; i < 14; i++) cx.tph[i] = 0;
+    const uint32_t lane = cx.lane;
+
+    for (;;) {
+        if (lane == 0) cx.CTL[5] = atomicAdd(p.next_task, 1u);
+        __syncthreads();
+        const uint32_t t = cx.CTL[5];
+        __syncthreads();
+        if (t >= p.ntasks) break;
+        cx.status = FS_OK;
+        const uint32_t qsel = p.t_qsel[t];
+        const uint8_t *qsrc = (qsel & HX_QUERY_SLOT) ? p.queries + (size_t)(qsel & 0x7fffffffu) * p.pitch : p.rows + (size_t)qsel * p.pitch;
+        f_park(p, qsrc, lane, cx.QV);
+        const int new_level = MODE == 1 ? p.t_level[t] : -1;
+        if (MODE == 1 && new_level >= FUSED_MAXL) { if (lane == 0) p.status[t] = FS_HOST; continue; }
+
+        // d(q, entry point): mod.rs:371-377 / scan.rs:475
+        if (lane == 0) cx.IDS[0] = p.entry;
+        __syncthreads();
+        const float d0 = f_dist_batch<OP, LPR>(p, cx.QV, cx.IDS, 1, lane);
+        cx.nd0 += 1;
+        if (lane == 0) cx.EP[0] = fh_pack(d0, p.entry);
+        __syncthreads();
+        uint32_t n_ep = 1;
+
+        // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
+        const int stop_above = MODE == 1 ? new_level : 0;
+        for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
+            f_search_layer<OP, LPR>(p, cx, n_ep, 1u, lc, MODE != 1);
+            const uint32_t wl = cx.CTL[1];
+            if (wl > 0) {
+                f_sort_results(cx, wl, MODE != 1);
+                if (MODE != 1) { const uint2 best = cx.EP[wl - 1]; __syncthreads(); if (lane == 0) cx.EP[0] = best; __syncthreads(); }
+                n_ep = 1;                         // MODE 1: ep = vec![w[0]]; EP[0] already is the nearest
+            } else if (MODE != 1) { n_ep = 0; break; }
+        }
+
+        if (MODE == 2) {
+            // get_scan_items + the amgettuple loop of an iterative scan (scan.rs:458-577, 794-875) for one query
+            uint32_t outc = 0; long long tuples = 0; double prev = -__builtin_inf();
+            cx.dlen = 0; cx.vcount = 0;
+            const size_t obase = (size_t)t * p.limit;
+            if (cx.status == FS_OK && n_ep > 0) {
+                f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, true, true);           // scan.rs:515-528
+                bool single = false;
+                for (;;) {
+                    if (cx.status != FS_OK) break;
+                    const uint32_t wl = single ? 1u : cx.CTL[1];
+                    if (!single) f_sort_results(cx, wl, true);                                   // EP[0..wl): nearest LAST
+                    // emit from the back (scan.rs:796-815, 860-874); the elements' TID masks are fetched 64 at a time
+                    uint32_t left = wl;
+                    while (left > 0 && outc < p.limit) {
+                        const uint32_t c = left < 64u ? left : 64u, base = left - c;
+                        if (lane < c) cx.IDS[lane] = p.emask[cx.EP[base + lane].y];
+                        __syncthreads();
+                        for (uint32_t i = c; i-- > 0 && outc < p.limit;) {
+                            const uint32_t em = cx.IDS[i]; const uint32_t nt = em >> 12;
+                            if (nt == 0) continue;                                               // scan.rs:866-868
+                            tuples++;
+                            const uint2 v = cx.EP[base + i]; const double dv = (double)fh_d(v);
+                            for (int ti = (int)nt - 1; ti >= 0 && outc < p.limit; ti--) {        // heaptids.pop()
+                                if (p.iter_mode == 2u) { if (dv < prev) continue; prev = dv; }   // strict_order, scan.rs:801-806
+                                if (!((em >> ti) & 1u)) continue;                                // the executor's filter rejects this tuple
+                                if (lane == 0) { p.out_ids[obase + outc] = v.y; p.out_d[obase + outc] = fh_d(v); p.out_tix[obase + outc] = (uint32_t)ti; }
+                                outc++;
+                            }
+                        }
+                        __syncthreads();
+                        left = base;
+                    }
+                    if (outc >= p.limit) break;
+                    if (tuples >= p.max_tuples) {                                                // scan.rs:831-841: drain `discarded` one by one
+                        if (cx.dlen == 0) break;
+                        const uint2 one = PHeap<true>::pop(cx.DS, cx.dlen, lane);
+                        __syncthreads(); if (lane == 0) cx.EP[0] = one; __syncthreads();
+                        single = true;
+                        continue;
+                    }
+                    if (cx.dlen == 0) break;                                                     // resume_scan_items, scan.rs:548-550
+                    single = false;
+                    n_ep = 0;
+                    while (n_ep < p.ef && cx.dlen > 0) {
+                        const uint2 x = PHeap<true>::pop(cx.DS, cx.dlen, lane);
+                        __syncthreads(); if (lane == 0) cx.EP[n_ep] = x; __syncthreads();
+                        n_ep++;
+                    }
+                    f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, false, false);
+                }
+            }
+            if (lane == 0) { p.out_cnt[t] = outc; p.status[t] = cx.status; }
+        } else if (MODE == 0) {
+            uint32_t cnt = 0;
+            if (cx.status == FS_OK && n_ep > 0) {
+                f_search_layer<OP, LPR>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
+                const uint32_t wl = cx.CTL[1];
+                f_sort_results(cx, wl, true);                                        // nearest LAST
+                cnt = wl < p.k ? wl : p.k;
+                for (uint32_t i = lane; i < cnt; i += 64) {                          // amgettuple pops from the back
+                    const uint2 v = cx.EP[wl - 1 - i];
+                    p.out_ids[(size_t)t * p.k + i] = v.y; p.out_d[(size_t)t * p.k + i] = fh_d(v);
+                }
+            }
+            if (lane == 0) { p.out_cnt[t] = cnt; p.status[t] = cx.status; }
+        } else {
+            const int start = new_level < p.entry_level ? new_level : p.entry_level;
+            const size_t obase = (size_t)t * FUSED_MAXL;
+            for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
+            for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
+                const uint32_t lm = lc == 0 ? lm0 : p.m;
+                f_search_layer<OP, LPR>(p, cx, n_ep, p.ef, lc, false);                // mod.rs:407-416
+                if (cx.status != FS_OK) break;
+                const uint32_t wl = cx.CTL[1];
+                f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
+                n_ep = wl;
+                // select_neighbors(W, lm): mod.rs:269-308
+                const unsigned long long ts0 = (p.fdbg & 4u) ? __builtin_amdgcn_s_memtime() : 0ull;
+                uint32_t r = 0, nd = 0;
+                if (wl <= lm) {
+                    for (uint32_t i = lane; i < wl; i += 64) cx.RL[i] = cx.EP[i];
+                    r = wl;
+                } else {
+                    // The candidate under test is parked in LDS; the NEXT candidate's row is fetched into the other of two
+                    // buffers (the select scratch in C's LDS part, and the query's slot: d(e, q) is already known, so the query is
+                    // not needed until the next layer's search and is parked again afterwards) while this one is compared.
+                    // Its neighbour list comes along: d(e, r) for an accepted r that is already one of e's neighbours is stored in
+                    // the mirror (the very bits a fresh evaluation gives: every term is symmetric in its operands), so a candidate
+                    // that one of those rules out costs no row traffic at all.
+                    uint8_t *const evb[2] = {cx.EV, cx.QV};
+                    uint32_t nx_id = 0xFFFFFFFFu; float nx_d = 0.0f;                  // lane's slot of the NEXT candidate's list (id, stored distance)
+                    auto list_prefetch = [&](uint32_t el) {
+                        const uint32_t *li; const float *ld; uint32_t lc_n;
+                        if (lc == 0) { li = p.l0_ids + (size_t)el * lm0; ld = p.l0_d + (size_t)el * lm0; lc_n = p.l0_cnt[el]; }
+                        else { const uint32_t blk = p.up_block[el] + (uint32_t)(lc - 1); li = p.up_ids + (size_t)blk * p.m; ld = p.up_d + (size_t)blk * p.m; lc_n = p.up_cnt[blk]; }
+                        nx_id = 0xFFFFFFFFu; nx_d = 0.0f;
+                        if (lane < lc_n) { nx_id = li[lane]; nx_d = ld[lane]; }
+                    };
+                    for (uint32_t i = 0; i < wl; i++) {
+                        if (r >= lm) break;                                          // mod.rs:285-287
+                        const uint2 e = cx.EP[i];
+                        bool closer = true;                                          // check_element_closer, mod.rs:315-339
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // e's own row and list (requested one iteration ago) have landed
+                        __syncthreads();
+                        const uint32_t my_id = nx_id; const float my_d = nx_d;       // e's list slot of this lane
+                        if (i + 1u < wl) { const uint32_t en = cx.EP[i + 1u].y; f_park_async(p, p.rows + (size_t)en * p.pitch, lane, evb[(i + 1u) & 1u]); list_prefetch(en); }
+                        if (r > 0 && i > 0) {
+                            bool known_hit = false;
+                            if (my_id != 0xFFFFFFFFu && my_d <= fh_d(e)) for (uint32_t j = 0; j < r; j++) known_hit |= cx.RL[j].y == my_id;
+                            if (__ballot(known_hit) != 0ull) closer = false;         // mod.rs:333-335 with a distance we already hold
+                        }
+                        if (r > 0 && closer) {
+                            if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
+                            __syncthreads();
+                            closer = !f_any_le<OP, LPR>(p, evb[i & 1u], cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
+                            __syncthreads();
+                        }
+                        if (lane == 0) { if (closer) cx.RL[r] = e; else cx.DL[nd] = e; }
+                        if (closer) r++; else nd++;
+                        __syncthreads();
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no row may still be in flight towards the query's slot
+                    __syncthreads();
+                    f_park(p, qsrc, lane, cx.QV);                                    // the query again, for the next layer's search
+                    if (lane == 0) for (uint32_t j = 0; j < nd && r < lm; j++) cx.RL[r++] = cx.DL[j];   // mod.rs:300-305
+                    r = __shfl(r, 0, 64);
+                }
+                __syncthreads();
+                const size_t lb = ((size_t)t * FUSED_MAXL + (size_t)lc) * lm0;
+                for (uint32_t i = lane; i < r; i += 64) { const uint2 v = cx.RL[i]; p.out_ids[lb + i] = v.y; p.out_d[lb + i] = fh_d(v); }
+                if (lane == 0) p.out_cnt[obase + lc] = r;
+                __syncthreads();
+                if (p.fdbg & 4u) cx.tph[13] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts0);
+            }
+            if (lane == 0) p.status[t] = cx.status;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax);
+                     if (p.fdbg & 4u) { for (int i = 0; i < 14; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
+}
+
+template <class OP, int MODE, int LPR>
+static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds)
+{
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t s = hipFuncSetAttribute((const void *)k_fused<OP, MODE, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (s != hipSuccess) return s;
+        attr_set = true;
+    }
+    if (getenv("HX_DEBUG")) {
+        static thread_local bool once = false;
+        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_fused<OP, MODE, LPR>, 64, lds);
+            fprintf(stderr, "[hx] k_fused<mode %d, %d lanes/row>: dynamic LDS %zu B, grid %u, occupancy API says %d blocks/CU\n", MODE, LPR, lds, grid, nb); }
+    }
+    hipLaunchKernelGGL((k_fused<OP, MODE, LPR>), dim3(grid), dim3(64), lds, e->stream, p);
+    return hipGetLastError();
+}
+
+template <class OP, int LPR>
+static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
+{
+    if (mode == 2) return launch_fused<OP, 2, LPR>(e, p, grid, lds);
+    return mode == 0 ? launch_fused<OP, 0, LPR>(e, p, grid, lds) : launch_fused<OP, 1, LPR>(e, p, grid, lds);
+}
+template <class OP>
+static hipError_t launch_fused_mode(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
+{   // lanes per row by payload, as in launch_links_cached
+    if (e->pitch <= 128) return launch_fused_lpr<OP, 8>(e, p, grid, lds, mode);
+    if (e->pitch <= 512) return launch_fused_lpr<OP, 32>(e, p, grid, lds, mode);
+    return launch_fused_lpr<OP, 64>(e, p, grid, lds, mode);
+}
+

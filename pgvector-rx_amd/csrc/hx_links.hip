@@ -1,0 +1,715 @@
+// hx_links.hip -- update_neighbor_connections (graph/mod.rs:442-489) on the device: k_links (uncached, 512 threads per list),
+// k_links_cached (one wavefront per list, pair matrix resident in HBM) and k_links_hub (speculating waves for hub lists),
+// plus their host-side launch code.  Own translation unit: compiles in parallel with the traversal kernel.
+#include "hx_fused_core.h"
+
+// =================================================================================================
+// K3 k_links: update_neighbor_connections (graph/mod.rs:442-489) for one (target, layer) list per 512-thread workgroup.
+//   The list (ids + distances) comes from the device mirror into LDS; the group's back-link ops are applied in
+//   insertion order: append while there is room (mod.rs:469-471); otherwise candidates = list + new, stable sort by
+//   distance (rank sort), the <= 33 candidate rows are staged through LDS exactly as in K2 (1 KiB chunks, register
+//   prefetch, double buffer) to form the lower-triangular pair matrix in LDS, and one wavefront runs
+//   select_neighbors / check_element_closer (mod.rs:269-339) on that matrix.  The new list goes back to the mirror
+//   and to the host.  Distances use the canonical order, so the result is bit-identical to the lock-step path.
+// =================================================================================================
+#define LK_MAXN 33            /* lm + 1 with lm <= 32 */
+#define LK_STAGE 5
+#ifndef LK_MINW
+#define LK_MINW 4
+#endif
+
+struct LinksParams {
+    const uint8_t *rows; uint32_t pitch, m;
+    uint32_t *l0_ids; float *l0_d; uint16_t *l0_cnt; const uint32_t *up_block; uint32_t *up_ids; float *up_d; uint16_t *up_cnt;
+    uint32_t n_groups; const uint32_t *target, *layer, *op_off, *op_new; const float *op_d;
+    const uint32_t *gmap;   // launch index -> group (nullptr: identity); the groups of a batch are split between k_links_cached and k_links_hub
+    uint32_t *out_ids; float *out_d; uint32_t *out_cnt; unsigned long long *n_pairs;
+    uint32_t dbg;   // timing experiments only (HX_LK_DBG): 1 skip pair math, 2 skip row loads, 4 skip select
+};
+
+template <class OP>
+__global__ void __launch_bounds__(HX_PAIR_WG, LK_MINW)
+k_links(const LinksParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t buf_bytes = LK_MAXN * 1024u;
+    uint8_t *bufs = lds;                                         // 2 x 33 KiB row-chunk buffers
+    uint32_t *lid = (uint32_t *)(lds + 2 * buf_bytes);           // current list ids [40]
+    float *ld = (float *)(lid + 40);                             // current list distances [40]
+    uint32_t *sid = (uint32_t *)(ld + 40);                       // sorted candidates [40]
+    float *sd = (float *)(sid + 40);
+    float *tri = sd + 40;                                        // pair matrix, packed lower triangle [528]
+    uint32_t *sel = (uint32_t *)(tri + HX_PAIR_SLAB);            // R indices [40], discarded indices [40], ctl [8]
+    uint32_t *dis = sel + 40; uint32_t *ctl = dis + 40;
+
+    const uint32_t g = blockIdx.x;
+    if (g >= p.n_groups) return;
+    if (p.dbg & 8u) return;
+    const uint32_t target = p.target[g], layer = p.layer[g];
+    const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
+    if (layer == 0) { gl_ids = p.l0_ids + (size_t)target * 2u * p.m; gl_d = p.l0_d + (size_t)target * 2u * p.m; gl_cnt = p.l0_cnt + target; }
+    else { const uint32_t blk = p.up_block[target] + layer - 1; gl_ids = p.up_ids + (size_t)blk * p.m; gl_d = p.up_d + (size_t)blk * p.m; gl_cnt = p.up_cnt + blk; }
+    uint32_t cnt = *gl_cnt;
+    if (threadIdx.x < cnt) { lid[threadIdx.x] = gl_ids[threadIdx.x]; ld[threadIdx.x] = gl_d[threadIdx.x]; }
+    __syncthreads();
+    unsigned long long pairs = 0;
+
+    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
+        if (p.dbg & 16u) break;
+        const uint32_t new_id = p.op_new[op]; const float new_d = p.op_d[op];
+        if (cnt < lm) {                                                            // mod.rs:469-471
+            if (threadIdx.x == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
+            cnt++;
+            __syncthreads();
+            continue;
+        }
+        const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
+        if (threadIdx.x == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
+        __syncthreads();
+        if (threadIdx.x < n) {
+            const float d = ld[threadIdx.x]; uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) { const float dj = ld[j]; rank += (dj < d) || (dj == d && j < threadIdx.x); }
+            sid[rank] = lid[threadIdx.x]; sd[rank] = d;
+        }
+        __syncthreads();
+        // ---- pair matrix of the n candidate rows.  Rows 1..n-1 of the triangle are paired (r, n-r) -- r + (n-r) = n <= 33
+        // pairs per row-pair -- and wave w owns row-pairs q = w and q = 15 - w (r = q + 1).  For a row-pair, accumulator
+        // A[j] is pair (n-r, j), j < n-r, and A[32-j] is pair (r, j), j < r (disjoint because n <= 33).  A wave reads
+        // its 4 "a" fragments once per chunk and each b_j fragment once for up to 4 pairs: 36 LDS reads per chunk
+        // instead of 132, and 4 independent accumulation chains per read. ----
+        const uint32_t P = n * (n - 1) / 2;
+        uint32_t rr[2], hh[2]; bool use_r[2], use_h[2];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; q2++) {
+            const uint32_t q = q2 == 0 ? wave : 15u - wave;
+            const uint32_t r = q + 1, h = n - r;                   // r <= 16
+            use_h[q2] = r < n && h > r;                            // partner row strictly above r
+            use_r[q2] = r < n && h >= r;                           // r itself (also the lone middle row when h == r)
+            rr[q2] = r; hh[q2] = use_h[q2] ? h : 0u;
+        }
+        uint32_t rid[LK_STAGE];
+#pragma unroll
+        for (int t = 0; t < LK_STAGE; t++) { const uint32_t r = wave + t * HX_PAIR_WAVES; rid[t] = r < n ? sid[r] : 0u; }
+        typename OP::acc_t acc[HX_PAIRS_PER_WAVE];                 // [0..32] row-pair 0, [33..65] row-pair 1
+#pragma unroll
+        for (int s2 = 0; s2 < HX_PAIRS_PER_WAVE; s2++) OP::init(acc[s2]);
+        u4 pre[LK_STAGE];
+        auto prefetch = [&](uint32_t c0) {
+            const uint32_t off = c0 + lane * 16u;
+#pragma unroll
+            for (int t = 0; t < LK_STAGE; t++) {
+                u4 v = {0u, 0u, 0u, 0u};
+                if (wave + t * HX_PAIR_WAVES < n && off < p.pitch && !(p.dbg & 2u)) v = *(const u4 *)(p.rows + (size_t)rid[t] * p.pitch + off);
+                pre[t] = v;
+            }
+        };
+        prefetch(0);
+        uint32_t bufsel = 0;
+        for (uint32_t c0 = 0; c0 < p.pitch; c0 += 1024u, bufsel ^= 1u) {
+            uint8_t *buf = bufs + bufsel * buf_bytes;
+#pragma unroll
+            for (int t = 0; t < LK_STAGE; t++) {
+                const uint32_t r = wave + t * HX_PAIR_WAVES;
+                if (r < n) *(u4 *)(buf + r * 1024u + lane * 16u) = pre[t];
+            }
+            __syncthreads();
+            if (c0 + 1024u < p.pitch) prefetch(c0 + 1024u);
+            if (p.dbg & 1u) continue;
+            const u4 ar0 = *(const u4 *)(buf + rr[0] * 1024u + lane * 16u), ah0 = *(const u4 *)(buf + hh[0] * 1024u + lane * 16u);
+            const u4 ar1 = *(const u4 *)(buf + rr[1] * 1024u + lane * 16u), ah1 = *(const u4 *)(buf + hh[1] * 1024u + lane * 16u);
+            const uint32_t jmax = n - 1u;                          // largest row index any wave needs as "b" is n-2
+#pragma unroll
+            for (int j = 0; j < LK_MAXN - 1; j++) {
+                if ((uint32_t)j < jmax) {
+                    const u4 bj = *(const u4 *)(buf + (uint32_t)j * 1024u + lane * 16u);
+                    if (use_h[0] && (uint32_t)j < hh[0]) OP::add(acc[j], ah0, bj);
+                    if (use_r[0] && (uint32_t)j < rr[0]) OP::add(acc[32 - j], ar0, bj);
+                    if (use_h[1] && (uint32_t)j < hh[1]) OP::add(acc[33 + j], ah1, bj);
+                    if (use_r[1] && (uint32_t)j < rr[1]) OP::add(acc[33 + 32 - j], ar1, bj);
+                }
+            }
+        }
+        {
+            float res0 = 0.f, res1 = 0.f;
+            if (!(p.dbg & 32u)) reduce_pairs<OP, HX_PAIRS_PER_WAVE>(acc, lane, res0, res1);
+            // lane l holds accumulator l (< 64); lanes 0,1 also hold accumulators 64, 65
+#pragma unroll
+            for (int part = 0; part < 2; part++) {
+                const uint32_t sidx = part == 0 ? lane : 64u + lane;
+                const float val = part == 0 ? res0 : res1;
+                if (part == 1 && lane >= HX_PAIRS_PER_WAVE - 64) continue;
+                const uint32_t q2 = sidx >= 33u ? 1u : 0u, k = sidx - 33u * q2;
+                const uint32_t r = q2 ? rr[1] : rr[0], h = q2 ? hh[1] : hh[0];
+                const bool uh = q2 ? use_h[1] : use_h[0], ur = q2 ? use_r[1] : use_r[0];
+                if (uh && k < h) tri[h * (h - 1) / 2 + k] = val;
+                else if (ur && 32u - k < r) tri[r * (r - 1) / 2 + (32u - k)] = val;
+            }
+        }
+        pairs += P;
+        __syncthreads();
+        // ---- select_neighbors(candidates, lm) on the matrix: mod.rs:284-305 ----
+        if (wave == 0) {
+            uint32_t r = 0, nd = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                if (r >= lm) break;                                                // mod.rs:285-287
+                if (p.dbg & 4u) { if (lane == 0) sel[r] = i; r++; continue; }
+                const float ed = sd[i];
+                bool hit = false;
+                if (lane < r) { const uint32_t rj = sel[lane]; hit = tri[i * (i - 1) / 2 + rj] <= ed; }   // mod.rs:333-335
+                const bool closer = __ballot(hit) == 0ull;
+                if (lane == 0) { if (closer) sel[r] = i; else dis[nd] = i; }
+                if (closer) r++; else nd++;
+            }
+            if (lane == 0) { for (uint32_t j = 0; j < nd && r < lm; j++) sel[r++] = dis[j]; ctl[0] = r; }   // mod.rs:300-305
+        }
+        __syncthreads();
+        cnt = ctl[0];
+        if (threadIdx.x < cnt) { const uint32_t k = sel[threadIdx.x]; lid[threadIdx.x] = sid[k]; ld[threadIdx.x] = sd[k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < cnt) {
+        gl_ids[threadIdx.x] = lid[threadIdx.x]; gl_d[threadIdx.x] = ld[threadIdx.x];
+        if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x]; }
+    }
+    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, pairs); }
+}
+
+// =================================================================================================
+// K4b k_links_cached: the same update_neighbor_connections, one WAVEFRONT per (target, layer) list, with the list's pair
+//   matrix kept resident in HBM between batches (layer 0: 496 f32 per element = 2 GB per 1M rows -- cheap on 288 GB).
+//   A prune of a full list then needs only the 32 distances new-row <-> current neighbours (streamed exactly like an
+//   expansion: new row parked in LDS, neighbour rows 4 x 3 KiB at a time, canonical order) instead of all 528 pairs;
+//   select_neighbors runs on the cached matrix + those 32, and the matrix of the surviving list is written back.
+//   Pairs the cache does not hold yet (a list's first prune, or after the host rewrote the list) are computed first,
+//   row by row.  Cached values are the very bits a recomputation would give, so results equal k_links / the lock-step path.
+// =================================================================================================
+#define LC_SLOTS 32
+#ifndef LC_RB
+#define LC_RB FUSED_RB         /* rows in flight when a whole list is streamed; 8 was measured slower (spills at 4 waves/SIMD) */
+#endif
+#define LC_TRI (LC_SLOTS * (LC_SLOTS - 1) / 2)     /* 496 */
+__device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > j ? i * (i - 1) / 2 + j : j * (j - 1) / 2 + i; }
+
+// One back-link op (new_id at distance new_d) on the list held in LDS: update_neighbor_connections' body, mod.rs:458-487.
+// Runs in ONE wave (wave-level ordering only), on the list state (M, lid, ld, cnt, v) and the scratch arrays it is given.
+// SPEC == false: applies the op; returns true when the list was pruned (it is then in select order, its matrix complete).
+// SPEC == true: touches only the scratch arrays and answers "would this op change the list?" -- false only when it is certain
+// that the new row is the one left out and every survivor keeps its slot (then list, distances and matrix stay as they are).
+template <class OP, int LPR, bool SPEC>
+__device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
+                      float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, uint8_t *QV,
+                      uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist, unsigned long long *tk = nullptr)
+{
+    unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
+#define LC_TICK(k) do { if (tk) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[k] += t_ - tq; tq = t_; } } while (0)
+
+
+        if (cnt < lm) {                                                            // mod.rs:469-471
+            if (SPEC) return true;
+            if (lane == 0) { lid[cnt] = new_id; ld[cnt] = new_d; }
+            cnt++;
+            F_WSYNC();
+            return false;
+        }
+        // pairs among the current list that the cache lacks: slot s against slots < s
+        if (SPEC && v < cnt) return true;
+        for (uint32_t sl = v < 1 ? 1 : v; sl < cnt; sl++) {
+            if (lane < sl) IDS[lane] = lid[lane];
+            f_park_w(fp, p.rows + (size_t)lid[sl] * p.pitch, lane, QV);
+            const float d = f_dist_batch<OP, LPR, LC_RB>(fp, QV, IDS, sl, lane);
+            if (lane < sl) M[sl * (sl - 1) / 2 + lane] = d;
+            ndist += sl;
+            F_WSYNC();
+        }
+        v = cnt;
+        LC_TICK(0);                                                                // missing pairs of the matrix
+        // d(new row, slot) is evaluated LAZILY: a hub list (inner product on unnormalised rows sends thousands of back-links
+        // per batch to one list, all applied by this one wave in order) drops most newcomers after a few comparisons, so
+        // streaming all `cnt` neighbour rows per op would be a long serial chain of wasted loads.  Order of evaluation:
+        // the slots already accepted when the walk reaches the new row first (FUSED_RB at a time, stop at the first batch
+        // with a hit, like check_element_closer's early return), the remaining slots only if the new row stays in the list.
+        const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
+        {   // rank sort: every lane compares its distance with lane j's, read through the scalar unit (no LDS traffic)
+            const float d = lane < cnt ? ld[lane] : new_d; uint32_t rank = 0;
+            const unsigned int dbits = __builtin_bit_cast(unsigned int, d);
+            for (uint32_t j = 0; j < n; j++) {
+                const float dj = __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_readlane((int)dbits, (int)j));
+                rank += (dj < d) || (dj == d && j < lane);
+            }
+            if (lane < n) { pos[rank] = lane < cnt ? lane : LC_SLOTS; sd[rank] = d; }
+        }
+        F_WSYNC();
+        LC_TICK(1);                                                                // sort
+        // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
+        uint32_t r = 0, ndc = 0, n_done = 0;      // n_done: how many entries of the evaluation order ORD have their nd[]
+        bool ordered = false; unsigned long long amask = 0ull;   // slots accepted so far
+        uint32_t my_slot = 0;                      // lane j: slot of the j-th accepted candidate
+        auto finish_nd = [&]() {                  // all remaining d(new, slot)
+            if (!ordered) {
+                if (lane < cnt) { IDS[lane] = lid[lane]; ORD[lane] = lane; }
+                f_park_w(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
+                ordered = true;
+            }
+            if (n_done < cnt) {
+                const float d = f_dist_batch<OP, LPR, LC_RB>(fp, QV, IDS + n_done, cnt - n_done, lane);
+                if (lane < cnt - n_done) nd[ORD[n_done + lane]] = d;
+                ndist += cnt - n_done; n_done = cnt;
+            }
+            F_WSYNC();
+        };
+        for (uint32_t i = 0; i < n; i++) {
+            if (r >= lm) break;
+            const float ed = sd[i]; const uint32_t si = pos[i];
+            bool closer;
+            if (si == LC_SLOTS) {
+                LC_TICK(2);                                                        // walk so far
+                // accepted slots first in the evaluation order
+                const bool acc = lane < cnt && ((amask >> lane) & 1ull) != 0ull;
+                const unsigned long long am = amask, below = (1ull << lane) - 1ull;
+                const uint32_t na = (uint32_t)__popcll(am);
+                if (lane < cnt) {
+                    const uint32_t o = acc ? (uint32_t)__popcll(am & below) : na + (uint32_t)__popcll(~am & below);
+                    IDS[o] = lid[lane]; ORD[o] = lane;
+                }
+                f_park_w(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
+                ordered = true;
+                bool hit = false;
+                constexpr uint32_t B = f_step_rows<LPR>();
+                for (uint32_t j0 = 0; j0 < na && !hit; j0 += B) {
+                    const uint32_t nb = na - j0 < B ? na - j0 : B;
+                    const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + j0, nb, lane);
+                    if (lane < nb) nd[ORD[j0 + lane]] = d;
+                    ndist += nb; n_done = j0 + nb;
+                    hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
+                }
+                closer = !hit;
+                LC_TICK(3);                                                        // lazy distances of the new row
+                if (SPEC && closer) return true;                                   // the new row enters the list
+                if (closer) finish_nd();                                           // later candidates are compared with the new row
+            } else {
+                bool hit = false;
+                if (lane < r) {
+                    const uint32_t sj = my_slot;                                   // slot of the lane-th accepted candidate (== pos[sel[lane]])
+                    const float dij = sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)];
+                    hit = dij <= ed;                                               // mod.rs:333-335
+                }
+                closer = __ballot(hit) == 0ull;
+                if (closer) amask |= 1ull << si;
+            }
+            if (closer && lane == r) my_slot = si;
+            if (lane == 0) { if (closer) sel[r] = i; else dis[ndc] = i; }
+            if (closer) r++; else ndc++;
+            F_WSYNC();
+        }
+        if (lane == 0) for (uint32_t j = 0; j < ndc && r < lm; j++) sel[r++] = dis[j];   // mod.rs:300-305
+        r = __shfl(r, 0, 64);
+        F_WSYNC();
+        LC_TICK(2);
+        {   // unchanged iff the new row is the one left out AND the survivors keep their slots, in order: nothing to rebuild then
+            const bool ok = lane >= r || pos[sel[lane]] == lane;
+            const bool changed = __ballot(!ok) != 0ull;
+            if (SPEC) return changed;
+            if (!changed) { LC_TICK(4); return true; }            // (a pruned list stays in select order: still "pruned" for the caller)
+        }
+        {   // the new row's distances to every slot are needed only if it stays in the list
+            bool mine = lane < r && pos[sel[lane]] == LC_SLOTS;
+            if (__ballot(mine) != 0ull) finish_nd();
+        }
+        // surviving list and its pair matrix
+        if (lane < r) { const uint32_t sa = pos[sel[lane]]; lid2[lane] = sa == LC_SLOTS ? new_id : lid[sa]; ld2[lane] = sd[sel[lane]]; }
+        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) {
+            uint32_t a, b; tri_decode(idx, a, b);
+            const uint32_t sa = pos[sel[a]], sb = pos[sel[b]];
+            M2[idx] = sa == LC_SLOTS ? nd[sb] : (sb == LC_SLOTS ? nd[sa] : M[lc_tri(sa, sb)]);
+        }
+        F_WSYNC();
+        if (lane < r) { lid[lane] = lid2[lane]; ld[lane] = ld2[lane]; }
+        for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) M[idx] = M2[idx];
+        cnt = r; v = r;
+        F_WSYNC();
+        LC_TICK(4);                                                                // remaining distances + list / matrix rebuild
+            return true;
+#undef LC_TICK
+}
+
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64, 4)
+k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    float *M = (float *)lds;                       // pair matrix over list slots, packed lower triangle [528]
+    float *M2 = M + 528;
+    uint32_t *lid = (uint32_t *)(M2 + 528);        // list ids / distances to the target [40]
+    float *ld = (float *)(lid + 40);
+    uint32_t *lid2 = (uint32_t *)(ld + 40); float *ld2 = (float *)(lid2 + 40);
+    float *nd = ld2 + 40;                          // d(new row, slot j)
+    uint32_t *pos = (uint32_t *)(nd + 40);         // sorted candidate k -> slot (LC_SLOTS = the new row)
+    float *sd = (float *)(pos + 40);
+    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *ORD = dis + 40, *IDS = ORD + 40;   // IDS[64]
+    float *DSC = (float *)(IDS + 64);
+    uint8_t *QV = (uint8_t *)(DSC + 64);
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x >= p.n_groups) return;
+    const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
+    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u; fp.dsc = DSC;
+    const uint32_t target = p.target[g], layer = p.layer[g];
+    const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
+    uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
+    if (layer == 0) { gl_ids = p.l0_ids + (size_t)target * 2u * p.m; gl_d = p.l0_d + (size_t)target * 2u * p.m; gl_cnt = p.l0_cnt + target; }
+    else { const uint32_t blk = p.up_block[target] + layer - 1; gl_ids = p.up_ids + (size_t)blk * p.m; gl_d = p.up_d + (size_t)blk * p.m; gl_cnt = p.up_cnt + blk; }
+    uint32_t cnt = *gl_cnt;
+    const bool cached = layer == 0 && lm == LC_SLOTS && pm != nullptr;
+    uint32_t v = cached ? pm_valid[target] : 0u;                 // slots [0, v) have their pairs in the cache
+    if (v > cnt) v = 0;
+    if (lane < cnt) { lid[lane] = gl_ids[lane]; ld[lane] = gl_d[lane]; }
+    if (v > 1) { const float *src = pm + (size_t)target * LC_TRI; for (uint32_t i = lane; i < v * (v - 1) / 2; i += 64) M[i] = src[i]; }
+    __syncthreads();
+    unsigned long long ndist = 0;
+
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+    const bool tm = (p.dbg & 8u) != 0; const unsigned long long tk0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++)
+        (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr);
+    if (lane < cnt) {
+        gl_ids[lane] = lid[lane]; gl_d[lane] = ld[lane];
+        if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + lane] = lid[lane]; p.out_d[(size_t)g * 2u * p.m + lane] = ld[lane]; }
+    }
+    if (cached) {
+        float *dst = pm + (size_t)target * LC_TRI;
+        for (uint32_t i = lane; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64) dst[i] = M[i];
+        if (lane == 0) pm_valid[target] = (uint8_t)v;
+    }
+    if (lane == 0) { *gl_cnt = (uint16_t)cnt; if (p.out_cnt) p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
+    if (tm && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk[5] = __builtin_amdgcn_s_memtime() - tk0; for (int i = 0; i < 6; i++) atomicAdd(p.n_pairs + 1 + i, tk[i]); }
+}
+
+// =================================================================================================
+// K4c k_links_hub: the same per-list work for a list that receives a LONG chain of back-links in one batch (inner product on
+//   unnormalised rows: thousands of ops for one hub list, which one wave would apply one after the other).  Almost all of a
+//   hub's newcomers are left out again, so HUB_W waves evaluate the next HUB_W ops speculatively, each against the
+//   current list (lc_op<SPEC>: scratch only); the ops before the first one that would change the list are no-ops by
+//   construction, that one is applied by wave 0 with the ordinary code, and the rest are re-evaluated.  Same result as the
+//   one-wave kernel, op for op.
+// =================================================================================================
+#ifndef HUB_W
+#define HUB_W 8
+#endif
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64 * HUB_W, 1)
+k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t nchb = ((p.pitch + 1023u) / 1024u) * 1024u;
+    // shared: M[528] M2[528] lid[40] ld[40] lid2[40] ld2[40] ctl[16]; per wave: nd pos sd sel dis ORD [40 each] IDS[64] DSC[64] QV[nchb]
+    float *M = (float *)lds, *M2 = M + 528;
+    uint32_t *lid = (uint32_t *)(M2 + 528); float *ld = (float *)(lid + 40);
+    uint32_t *lid2 = (uint32_t *)(ld + 40); float *ld2 = (float *)(lid2 + 40);
+    uint32_t *ctl = (uint32_t *)(ld2 + 40);
+    uint8_t *wbase = (uint8_t *)(ctl + 16) + (size_t)wave * ((40 * 6 + 64 + 64) * 4 + nchb);
+    float *nd = (float *)wbase; uint32_t *pos = (uint32_t *)(nd + 40); float *sd = (float *)(pos + 40);
+    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *ORD = dis + 40, *IDS = ORD + 40;
+    float *DSC = (float *)(IDS + 64);
+    uint8_t *QV = (uint8_t *)(DSC + 64);
+    if (blockIdx.x >= p.n_groups) return;
+    const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
+    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u; fp.dsc = DSC;
+    const uint32_t target = p.target[g], layer = p.layer[g];
+    const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
+    uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
+    if (layer == 0) { gl_ids = p.l0_ids + (size_t)target * 2u * p.m; gl_d = p.l0_d + (size_t)target * 2u * p.m; gl_cnt = p.l0_cnt + target; }
+    else { const uint32_t blk = p.up_block[target] + layer - 1; gl_ids = p.up_ids + (size_t)blk * p.m; gl_d = p.up_d + (size_t)blk * p.m; gl_cnt = p.up_cnt + blk; }
+    const bool cached = layer == 0 && lm == LC_SLOTS && pm != nullptr;
+    uint32_t cnt = *gl_cnt;
+    uint32_t v = cached ? pm_valid[target] : 0u;
+    if (v > cnt) v = 0;
+    if (threadIdx.x < cnt) { lid[threadIdx.x] = gl_ids[threadIdx.x]; ld[threadIdx.x] = gl_d[threadIdx.x]; }
+    if (v > 1) { const float *src = pm + (size_t)target * LC_TRI; for (uint32_t i = threadIdx.x; i < v * (v - 1) / 2; i += 64 * HUB_W) M[i] = src[i]; }
+    const uint32_t op_end = p.op_off[g + 1];
+    if (threadIdx.x == 0) { ctl[0] = p.op_off[g]; ctl[1] = cnt; ctl[2] = v; ctl[3] = 0; }   // next op, |list|, cached slots, list is in select order
+    unsigned long long ndist = 0;
+    for (;;) {
+        __syncthreads();
+        const uint32_t op = ctl[0]; cnt = ctl[1]; v = ctl[2]; const bool canon = ctl[3] != 0;
+        if (op >= op_end) break;
+        if (!canon || cnt < lm || v < cnt) {                       // appends, the first prune, missing pairs: the ordinary path, one op
+            __syncthreads();
+            if (wave == 0) {
+                const bool pruned = lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist);
+                if (lane == 0) { ctl[0] = op + 1u; ctl[1] = cnt; ctl[2] = v; if (pruned) ctl[3] = 1u; }
+            }
+            continue;
+        }
+        const uint32_t nv = op_end - op < HUB_W ? op_end - op : HUB_W;   // ops evaluated this round
+        bool changed = false;
+        if (wave < nv) {
+            uint32_t c2 = cnt, v2 = v;
+            changed = lc_op<OP, LPR, true>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, c2, v2, lm, p.op_new[op + wave], p.op_d[op + wave], lane, ndist);
+        }
+        if (lane == 0) ctl[4 + wave] = changed ? 1u : 0u;
+        __syncthreads();
+        uint32_t first = nv;
+        for (uint32_t w = 0; w < nv; w++) if (ctl[4 + w]) { first = w; break; }
+        __syncthreads();
+        if (first == nv) { if (threadIdx.x == 0) ctl[0] = op + nv; continue; }
+        if (wave == 0) {
+            (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op + first], p.op_d[op + first], lane, ndist);
+            if (lane == 0) { ctl[0] = op + first + 1u; ctl[1] = cnt; ctl[2] = v; }
+        }
+    }
+    cnt = ctl[1]; v = ctl[2];
+    if (threadIdx.x < cnt) {
+        gl_ids[threadIdx.x] = lid[threadIdx.x]; gl_d[threadIdx.x] = ld[threadIdx.x];
+        if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x]; }
+    }
+    if (cached) {
+        float *dst = pm + (size_t)target * LC_TRI;
+        for (uint32_t i = threadIdx.x; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64 * HUB_W) dst[i] = M[i];
+        if (threadIdx.x == 0) pm_valid[target] = (uint8_t)v;
+    }
+    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; if (p.out_cnt) p.out_cnt[g] = cnt; }
+    if (lane == 0) atomicAdd(p.n_pairs, ndist);
+}
+
+template <class OP, int LPR>
+static hipError_t launch_links_cached_lpr(hx_engine *e, const LinksParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (528 * 2 + 40 * 11 + 64 + 64) * 4 + nch * 1024;
+    hipLaunchKernelGGL((k_links_cached<OP, LPR>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    return hipGetLastError();
+}
+template <class OP, int LPR>
+static hipError_t launch_links_hub_lpr(hx_engine *e, const LinksParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (528 * 2 + 40 * 4 + 16) * 4 + (size_t)HUB_W * ((40 * 6 + 64 + 64) * 4 + nch * 1024);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t st = hipFuncSetAttribute((const void *)k_links_hub<OP, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (st != hipSuccess) return st;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_links_hub<OP, LPR>), dim3(p.n_groups), dim3(64 * HUB_W), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    return hipGetLastError();
+}
+template <class OP>
+static hipError_t launch_links_hub(hx_engine *e, const LinksParams &p)
+{
+    if (e->pitch <= 128) return launch_links_hub_lpr<OP, 8>(e, p);
+    if (e->pitch <= 512) return launch_links_hub_lpr<OP, 32>(e, p);
+    return launch_links_hub_lpr<OP, 64>(e, p);
+}
+template <class OP>
+static hipError_t launch_links_cached(hx_engine *e, const LinksParams &p)
+{   // lanes per row by payload: <= 128 B (bit(1024), tiny test vectors) 8, <= 512 B (vector(128)) 32, else the whole wave
+    if (e->pitch <= 128) return launch_links_cached_lpr<OP, 8>(e, p);
+    if (e->pitch <= 512) return launch_links_cached_lpr<OP, 32>(e, p);
+    return launch_links_cached_lpr<OP, 64>(e, p);
+}
+
+template <class OP>
+static hipError_t launch_links(hx_engine *e, const LinksParams &p)
+{
+    const size_t lds = 2 * (size_t)LK_MAXN * 1024u + (40 * 4 + HX_PAIR_SLAB + 40 * 2 + 8) * 4;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t s = hipFuncSetAttribute((const void *)k_links<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (s != hipSuccess) return s;
+        attr_set = true;
+    }
+    if (getenv("HX_DEBUG")) {
+        static thread_local bool once = false;
+        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_links<OP>, HX_PAIR_WG, lds);
+            fprintf(stderr, "[hx] k_links: dynamic LDS %zu B, occupancy API says %d blocks/CU\n", lds, nb); }
+    }
+    hipLaunchKernelGGL((k_links<OP>), dim3(p.n_groups), dim3(HX_PAIR_WG), lds, e->stream, p);
+    return hipGetLastError();
+}
+
+int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
+                         const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs,
+                         bool want_lists)
+{
+    HxMirror &mr = mirror;
+    if (n_groups == 0) return HX_OK;
+    if (2 * mr.m + 1 > LK_MAXN) return fail(HX_E_ARG, "k_links handles m <= 16");
+    HX_HIP(this, hipSetDevice(device));
+    static const bool use_cache = !(getenv("HX_LINKS_NOCACHE") && atoi(getenv("HX_LINKS_NOCACHE")));
+    if (use_cache && 2 * mr.m == LC_SLOTS && pitch <= FUSED_MAXCH * 1024u && mr.cap_pm < mr.cap) {
+        // pair-matrix cache for every layer-0 list: 496 f32 per element
+        float *npm = nullptr; uint8_t *nv = nullptr;
+        HX_HIP(this, hipMalloc((void **)&npm, (size_t)mr.cap * LC_TRI * sizeof(float)));
+        HX_HIP(this, hipMalloc((void **)&nv, mr.cap));
+        HX_HIP(this, hipMemsetAsync(nv, 0, mr.cap, stream));
+        if (mr.d_pm && mr.cap_pm) {
+            HX_HIP(this, hipMemcpyAsync(npm, mr.d_pm, (size_t)mr.cap_pm * LC_TRI * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HX_HIP(this, hipMemcpyAsync(nv, mr.d_pm_valid, mr.cap_pm, hipMemcpyDeviceToDevice, stream));
+        }
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (mr.d_pm) (void)hipFree(mr.d_pm);
+        if (mr.d_pm_valid) (void)hipFree(mr.d_pm_valid);
+        mr.d_pm = npm; mr.d_pm_valid = nv; mr.cap_pm = mr.cap;
+    }
+    const bool cached_kernel = use_cache && mr.d_pm != nullptr && 2 * mr.m == LC_SLOTS;
+    const uint32_t n_ops = op_off[n_groups], lm0 = 2 * mr.m;
+    size_t o = 0;
+    const size_t o_ctr = o; o += 64;
+    const size_t o_tg = o; o += al16((size_t)n_groups * 4);
+    const size_t o_ly = o; o += al16((size_t)n_groups * 4);
+    const size_t o_off = o; o += al16(((size_t)n_groups + 1) * 4);
+    const size_t o_new = o; o += al16((size_t)n_ops * 4);
+    const size_t o_od = o; o += al16((size_t)n_ops * 4);
+    const size_t o_gmap = o; o += al16((size_t)n_groups * 4);   // launch order: hub lists first, then the rest
+    const size_t in_bytes = o;
+    const size_t o_cnt = o; o += al16((size_t)n_groups * 4);
+    const size_t o_ids = o; o += al16((size_t)n_groups * lm0 * 4);
+    const size_t o_d = o; o += al16((size_t)n_groups * lm0 * 4);
+    if (o > mr.cap_lk) {
+        if (mr.h_lk) (void)hipHostFree(mr.h_lk);
+        if (mr.d_lk) (void)hipFree(mr.d_lk);
+        mr.h_lk = mr.d_lk = nullptr; mr.cap_lk = 0;
+        const size_t n = o * 2;
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_lk, n, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&mr.d_lk, n));
+        mr.cap_lk = n;
+    }
+    uint8_t *h = mr.h_lk;
+    memset(h + o_ctr, 0, 64);
+    memcpy(h + o_tg, target, (size_t)n_groups * 4); memcpy(h + o_ly, layer, (size_t)n_groups * 4);
+    memcpy(h + o_off, op_off, ((size_t)n_groups + 1) * 4);
+    memcpy(h + o_new, op_new, (size_t)n_ops * 4); memcpy(h + o_od, op_d, (size_t)n_ops * 4);
+    uint32_t n_hub = 0;
+    {   // lists with a long chain of ops go to the speculative multi-wave kernel (k_links_hub); HX_HUB_MIN=0 disables it
+        static const uint32_t hub_min = getenv("HX_HUB_MIN") ? (uint32_t)atoi(getenv("HX_HUB_MIN")) : 48u;
+        uint32_t *gm = (uint32_t *)(h + o_gmap);
+        if (cached_kernel && hub_min) for (uint32_t g = 0; g < n_groups; g++) if (op_off[g + 1] - op_off[g] >= hub_min) gm[n_hub++] = g;
+        uint32_t k = n_hub;
+        if (n_hub) { for (uint32_t g = 0; g < n_groups; g++) if (op_off[g + 1] - op_off[g] < hub_min) gm[k++] = g; }
+        else for (uint32_t g = 0; g < n_groups; g++) gm[g] = g;
+    }
+    HX_HIP(this, hipMemcpyAsync(mr.d_lk, h, in_bytes, hipMemcpyHostToDevice, stream));
+    LinksParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.m = mr.m;
+    p.l0_ids = mr.d_l0_ids; p.l0_d = mr.d_l0_d; p.l0_cnt = mr.d_l0_cnt; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_d = mr.d_up_d; p.up_cnt = mr.d_up_cnt;
+    p.n_groups = n_groups; p.target = (const uint32_t *)(mr.d_lk + o_tg); p.layer = (const uint32_t *)(mr.d_lk + o_ly);
+    p.op_off = (const uint32_t *)(mr.d_lk + o_off); p.op_new = (const uint32_t *)(mr.d_lk + o_new); p.op_d = (const float *)(mr.d_lk + o_od);
+    p.out_ids = (uint32_t *)(mr.d_lk + o_ids); p.out_d = (float *)(mr.d_lk + o_d); p.out_cnt = (uint32_t *)(mr.d_lk + o_cnt);
+    p.n_pairs = (unsigned long long *)(mr.d_lk + o_ctr);
+    p.gmap = nullptr;
+    { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+    if (cached_kernel) {
+        if (n_hub) {
+            LinksParams ph = p; ph.n_groups = n_hub; ph.gmap = (const uint32_t *)(mr.d_lk + o_gmap);
+#define F32C(K) ls = launch_links_hub<OpF32<K>>(this, ph)
+#define F16C(K) ls = launch_links_hub<OpF16<K>>(this, ph)
+            HX_DISPATCH(this, F32C, F16C, ls = launch_links_hub<OpHamming>(this, ph), ls = launch_links_hub<OpJaccard>(this, ph));
+#undef F32C
+#undef F16C
+            HX_HIP(this, ls);
+            p.gmap = (const uint32_t *)(mr.d_lk + o_gmap) + n_hub; p.n_groups = n_groups - n_hub;
+        }
+        if (p.n_groups) {
+#define F32C(K) ls = launch_links_cached<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_links_cached<OpF16<K>>(this, p)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links_cached<OpHamming>(this, p), ls = launch_links_cached<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+        }
+    } else {
+#define F32C(K) ls = launch_links<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_links<OpF16<K>>(this, p)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links<OpHamming>(this, p), ls = launch_links<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+    }
+    HX_HIP(this, ls);
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(h + o_ctr, mr.d_lk + o_ctr, 64, hipMemcpyDeviceToHost, stream));
+    if (want_lists) HX_HIP(this, hipMemcpyAsync(h + o_cnt, mr.d_lk + o_cnt, o - o_cnt, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    *out_cnt = (const uint32_t *)(h + o_cnt); *out_ids = (const uint32_t *)(h + o_ids); *out_d = (const float *)(h + o_d);
+    unsigned long long np; memcpy(&np, h + o_ctr, 8);
+    if (p.dbg & 8u) { unsigned long long t[7]; memcpy(t, h + o_ctr, 56); fprintf(stderr, "[hx] k_links_cached groups %u ops %u: ticks matrix-fill %llu sort %llu walk %llu lazy-nd %llu rebuild %llu; whole kernel per wave %llu\n", n_groups, n_ops, t[1], t[2], t[3], t[4], t[5], t[6]); }
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    return HX_OK;
+}
+
+int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys, const uint32_t *op_new, const float *op_d, uint64_t *n_pairs, uint32_t stats[2])
+{
+    HxMirror &mr = mirror;
+    stats[0] = stats[1] = 0;
+    if (n_pairs) *n_pairs = 0;
+    if (n_ops == 0) return HX_OK;
+    if (2 * mr.m != LC_SLOTS || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "device-side op grouping serves m = 16 and rows <= 8 KiB");
+    HX_HIP(this, hipSetDevice(device));
+    if (mr.cap_pm < mr.cap) {                                   // pair-matrix cache for every layer-0 list (as in links_run)
+        float *npm = nullptr; uint8_t *nv = nullptr;
+        HX_HIP(this, hipMalloc((void **)&npm, (size_t)mr.cap * LC_TRI * sizeof(float)));
+        HX_HIP(this, hipMalloc((void **)&nv, mr.cap));
+        HX_HIP(this, hipMemsetAsync(nv, 0, mr.cap, stream));
+        if (mr.d_pm && mr.cap_pm) {
+            HX_HIP(this, hipMemcpyAsync(npm, mr.d_pm, (size_t)mr.cap_pm * LC_TRI * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            HX_HIP(this, hipMemcpyAsync(nv, mr.d_pm_valid, mr.cap_pm, hipMemcpyDeviceToDevice, stream));
+        }
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (mr.d_pm) (void)hipFree(mr.d_pm);
+        if (mr.d_pm_valid) (void)hipFree(mr.d_pm_valid);
+        mr.d_pm = npm; mr.d_pm_valid = nv; mr.cap_pm = mr.cap;
+    }
+    if (mr.cap_lk < 256) {                                      // counters live in the links staging buffers
+        if (mr.h_lk) (void)hipHostFree(mr.h_lk);
+        if (mr.d_lk) (void)hipFree(mr.d_lk);
+        mr.h_lk = mr.d_lk = nullptr; mr.cap_lk = 0;
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_lk, 4096, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&mr.d_lk, 4096));
+        mr.cap_lk = 4096;
+    }
+    static const uint32_t hub_min = getenv("HX_HUB_MIN") ? (uint32_t)atoi(getenv("HX_HUB_MIN")) : 48u;
+    uint32_t c[4];
+    int rc = hx_group_ops(this, n_ops, keys, op_new, op_d, hub_min, grp, c);
+    if (rc) return rc;
+    const uint32_t n_groups = c[0], n_hub = c[1], n_norm = c[2];
+    stats[0] = n_groups; stats[1] = c[3];
+    LinksParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.m = mr.m;
+    p.l0_ids = mr.d_l0_ids; p.l0_d = mr.d_l0_d; p.l0_cnt = mr.d_l0_cnt; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_d = mr.d_up_d; p.up_cnt = mr.d_up_cnt;
+    p.n_groups = n_groups; p.target = grp.tg; p.layer = grp.ly; p.op_off = grp.off; p.op_new = grp.op_new; p.op_d = grp.op_d; p.gmap = nullptr;
+    p.out_ids = nullptr; p.out_d = nullptr; p.out_cnt = nullptr;
+    p.n_pairs = (unsigned long long *)mr.d_lk;
+    { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
+    HX_HIP(this, hipMemsetAsync(mr.d_lk, 0, 64, stream));
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+    if (n_hub) {
+        LinksParams ph = p; ph.n_groups = n_hub; ph.gmap = grp.gmap_hub;
+#define F32C(K) ls = launch_links_hub<OpF32<K>>(this, ph)
+#define F16C(K) ls = launch_links_hub<OpF16<K>>(this, ph)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links_hub<OpHamming>(this, ph), ls = launch_links_hub<OpJaccard>(this, ph));
+#undef F32C
+#undef F16C
+        HX_HIP(this, ls);
+    }
+    if (n_norm) {
+        p.n_groups = n_norm; p.gmap = grp.gmap_norm;
+#define F32C(K) ls = launch_links_cached<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_links_cached<OpF16<K>>(this, p)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_links_cached<OpHamming>(this, p), ls = launch_links_cached<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+        HX_HIP(this, ls);
+    }
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk, mr.d_lk, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    unsigned long long np; memcpy(&np, mr.h_lk, 8);
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    return HX_OK;
+}
