@@ -180,6 +180,32 @@ int hx_index_batch_export_links(const hx_index *ix, void *buf);                 
 int hx_index_batch_import_links(hx_index *ix, const void *buf, uint64_t nbytes); /* any rank's export */
 int hx_index_batch_end(hx_index *ix, uint32_t *elem_out);
 
+/* The same batch with the members' neighbour lists kept in DEVICE memory from the traversal kernel to the back-link kernels
+ * (what hx_index_insert does by itself whenever hx_index_dbatch_supported; the reference builds one row at a time on one core,
+ * build.rs:400-535, handler.rs:153-154).  Buffers are device pointers owned by the caller -- a multi-GPU build all-gathers them
+ * (RCCL) between the stages without a host copy:
+ *   supported          : 1 when a batch with these level draws can run device-resident (m <= 16, rows <= 8 KiB, no level beyond the
+ *                        traversal kernel's 8 layers); otherwise use hx_index_batch_* for that batch
+ *   record_bytes       : bytes of one member record (cnt[8] | ids[8][2m] | d[8][2m], 32-bit words)
+ *   list_record_bytes  : bytes of one pruned-list record {target, layer, cnt, ids[2m], d[2m]}
+ *   begin              : as hx_index_batch_begin (every rank)
+ *   search             : find_element_neighbors for members [lo, hi); record of member i at d_records + (i - lo) * record_bytes
+ *   links              : d_records = all b member records (record i = member i).  Every rank merges duplicates / moves the entry point and
+ *                        scatters the members' lists into its graph copy; then prunes the back-link lists it owns (target % world == rank).
+ *                        *n_list_records = lists it pruned (0 when world == 1)
+ *   export_links       : copies this rank's list records to d_out (device)
+ *   import_links       : scatters n list records of another rank into the graph copy
+ *   end                : closes the batch; elem_out[i] = element holding tid i */
+int hx_index_dbatch_supported(const hx_index *ix, const int32_t *levels, uint32_t b);
+uint64_t hx_index_dbatch_record_bytes(const hx_index *ix);
+uint64_t hx_index_dbatch_list_record_bytes(const hx_index *ix);
+int hx_index_dbatch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids);
+int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_records);
+int hx_index_dbatch_links(hx_index *ix, uint32_t rank, uint32_t world, const void *d_records, uint64_t *n_list_records);
+int hx_index_dbatch_export_links(hx_index *ix, void *d_out);
+int hx_index_dbatch_import_links(hx_index *ix, const void *d_list_records, uint64_t n);
+int hx_index_dbatch_end(hx_index *ix, uint32_t *elem_out);
+
 /* graph export (what create_graph_pages/write_neighbor_tuples serialise, build.rs:545-821) */
 uint32_t hx_index_size(const hx_index *ix);
 int64_t hx_index_entry(const hx_index *ix);                   /* -1 = empty */

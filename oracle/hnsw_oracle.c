@@ -617,8 +617,19 @@ ORC_API int orc_index_insert(orc_index *x, const void *row, int level, int64_t t
  * duplicate merge / back-links / entry-point update of build.rs:482-525 are applied.  A row merged
  * as a duplicate stays in the arena as a tombstone (merged=1, no links) because later rows of the
  * batch already hold their indices.  n==1 is exactly orc_index_insert apart from the tombstone.
+ * Identical rows INSIDE one batch cannot find each other through the graph (they are not linked yet), so the
+ * duplicate test of build.rs:482-512 is completed for them in the order the sequential schedule would meet them:
+ * first the zero-distance layer-0 neighbours (find_duplicate), then the earliest byte-identical member of this
+ * batch that is still an element of its own and has room for another heap TID (HNSW_HEAPTIDS).  20 identical rows
+ * in one batch therefore end as 2 elements of 10 TIDs, as they do one row at a time (tests/t/015).
  * out_idx[i] = element that holds tid i.
  */
+static uint64_t row_hash(const uint8_t *p, size_t n)
+{
+    uint64_t h = 0xcbf29ce484222325ull;                     /* FNV-1a: only used to bucket candidates, equality is memcmp */
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
 ORC_API void orc_index_insert_batch(orc_index *x, const void *rows, const int *levels, const int64_t *tids, int n, int *out_idx)
 {
     const uint8_t *r = rows;
@@ -630,10 +641,34 @@ ORC_API void orc_index_insert_batch(orc_index *x, const void *rows, const int *l
         push_element(x, r + (size_t)i * x->row_bytes, lv);
     }
     for (int i = i0; i < n; i++) find_element_neighbors(x, first + (i - i0), entry_idx);
+    /* members bucketed by payload hash, each bucket chained in row order */
+    int nb = n - i0, tsize = 16; while (tsize < 2 * nb) tsize <<= 1;
+    int *head = malloc((size_t)tsize * sizeof(int)), *tail = malloc((size_t)tsize * sizeof(int)), *next = malloc((size_t)(nb + 1) * sizeof(int));
+    int *bucket = malloc((size_t)(nb + 1) * sizeof(int));
+    uint64_t *hk = malloc((size_t)tsize * sizeof(uint64_t));
+    for (int t = 0; t < tsize; t++) head[t] = tail[t] = -1;
+    for (int k = 0; k < nb; k++) {
+        uint64_t h = row_hash(rowp(x, first + k), x->row_bytes);
+        int t = (int)(h & (uint64_t)(tsize - 1));
+        while (head[t] >= 0 && hk[t] != h) t = (t + 1) & (tsize - 1);
+        if (head[t] < 0) { head[t] = k; hk[t] = h; } else next[tail[t]] = k;
+        tail[t] = k; next[k] = -1; bucket[k] = t;
+    }
     for (int i = i0; i < n; i++) {
         int new_idx = first + (i - i0);
         int dup = find_duplicate(x, new_idx);
-        if (dup >= 0 && !x->el[dup].merged) {
+        if (dup >= 0 && x->el[dup].merged) dup = -1;
+        if (dup < 0) {
+            int t = bucket[i - i0];
+            /* members that are merged or full never become eligible again: the bucket's head moves past them */
+            while (head[t] >= 0 && head[t] < i - i0 && (x->el[first + head[t]].merged || x->el[first + head[t]].ntids >= HNSW_HEAPTIDS)) head[t] = next[head[t]];
+            for (int k = head[t]; k >= 0 && k < i - i0; k = next[k]) {
+                elem_t *c = &x->el[first + k];
+                if (c->merged || c->ntids >= HNSW_HEAPTIDS) continue;
+                if (memcmp(rowp(x, new_idx), rowp(x, first + k), x->row_bytes) == 0) { dup = first + k; break; }
+            }
+        }
+        if (dup >= 0) {
             x->el[dup].tids[x->el[dup].ntids++] = tids[i];
             elem_t *e = &x->el[new_idx];
             for (int l = 0; l <= e->level; l++) e->ncnt[l] = 0;
@@ -648,6 +683,7 @@ ORC_API void orc_index_insert_batch(orc_index *x, const void *rows, const int *l
         x->ind_tuples += 1.0;
         if (out_idx) out_idx[i] = new_idx;
     }
+    free(head); free(tail); free(next); free(bucket); free(hk);
 }
 
 /* ---- accessors used by tests ---- */

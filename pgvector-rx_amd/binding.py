@@ -73,6 +73,15 @@ def lib():
         "hx_index_batch_export_links": (i32, [vp, vp]),
         "hx_index_batch_import_links": (i32, [vp, vp, u64]),
         "hx_index_batch_end": (i32, [vp, vp]),
+        "hx_index_dbatch_supported": (i32, [vp, vp, u32]),
+        "hx_index_dbatch_record_bytes": (u64, [vp]),
+        "hx_index_dbatch_list_record_bytes": (u64, [vp]),
+        "hx_index_dbatch_begin": (i32, [vp, u64, u32, vp, vp]),
+        "hx_index_dbatch_search": (i32, [vp, u32, u32, vp]),
+        "hx_index_dbatch_links": (i32, [vp, u32, u32, vp, C.POINTER(u64)]),
+        "hx_index_dbatch_export_links": (i32, [vp, vp]),
+        "hx_index_dbatch_import_links": (i32, [vp, vp, u64]),
+        "hx_index_dbatch_end": (i32, [vp, vp]),
         "hx_index_size": (u32, [vp]),
         "hx_index_entry": (i64, [vp]),
         "hx_index_level": (i32, [vp, u32]),
@@ -308,6 +317,43 @@ class Index:
     def batch_end(self, n):
         out = np.empty(n, np.uint32)
         self._ck(lib().hx_index_batch_end(self.h, _p(out)))
+        return out
+
+    # ---- device-resident staged batch: the buffers are DEVICE pointers (ints), e.g. torch tensors' data_ptr() ----
+    def dbatch_supported(self, levels):
+        levels = np.ascontiguousarray(levels, np.int32)
+        return bool(lib().hx_index_dbatch_supported(self.h, _p(levels), len(levels)))
+
+    @property
+    def dbatch_record_bytes(self):
+        return lib().hx_index_dbatch_record_bytes(self.h)
+
+    @property
+    def dbatch_list_record_bytes(self):
+        return lib().hx_index_dbatch_list_record_bytes(self.h)
+
+    def dbatch_begin(self, first_row, levels, tids):
+        levels = np.ascontiguousarray(levels, np.int32)
+        tids = np.ascontiguousarray(tids, np.int64)
+        self._ck(lib().hx_index_dbatch_begin(self.h, first_row, len(levels), _p(levels), _p(tids)))
+
+    def dbatch_search(self, lo, hi, d_records):
+        self._ck(lib().hx_index_dbatch_search(self.h, lo, hi, C.c_void_p(d_records)))
+
+    def dbatch_links(self, rank, world, d_records):
+        n = C.c_uint64(0)
+        self._ck(lib().hx_index_dbatch_links(self.h, rank, world, C.c_void_p(d_records), C.byref(n)))
+        return n.value
+
+    def dbatch_export_links(self, d_out):
+        self._ck(lib().hx_index_dbatch_export_links(self.h, C.c_void_p(d_out)))
+
+    def dbatch_import_links(self, d_list_records, n):
+        self._ck(lib().hx_index_dbatch_import_links(self.h, C.c_void_p(d_list_records), n))
+
+    def dbatch_end(self, n):
+        out = np.empty(n, np.uint32)
+        self._ck(lib().hx_index_dbatch_end(self.h, _p(out)))
         return out
 
     @property

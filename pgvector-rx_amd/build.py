@@ -20,6 +20,7 @@ SOURCES = {
     "hx_links.hip": ["hx_ops.h", "hx_fused_core.h"],
     "hx_mfma.hip": ["hx_ops.h"],
     "hx_group.hip": [],
+    "hx_batch.hip": ["hx_ops.h"],
     "hx_index.cpp": [],
 }
 # -ffp-contract=off: mul and add are rounded separately, as in the reference's unfused Rust

@@ -134,13 +134,14 @@ int hx_engine::mirror_download(uint64_t n_elems, uint64_t n_blocks, uint32_t *l0
 // [ntasks][FUSED_MAXL][2m], out_cnt [ntasks][FUSED_MAXL].  status[ntasks].  All host pointers.
 int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                          uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                         uint64_t counts[2], const HxFusedIter *it, HxFusedView *view, uint32_t roomy)
+                         uint64_t counts[2], const HxFusedIter *it, HxFusedView *view, uint32_t roomy, const HxFusedDev *dev)
 {
     HxMirror &mr = mirror;
     if (ntasks == 0) return HX_OK;
     if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_ARG, "row too wide for the fused kernel");
     if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
     if (mode == 2 && (!it || !it->emask || !it->out_tix)) return fail(HX_E_ARG, "iterative scan arguments missing");
+    if (dev && mode != 1) return fail(HX_E_ARG, "device-resident results are an insert-mode feature");
     HX_HIP(this, hipSetDevice(device));
     // LDS: C[ccap] W[ef+2] EP[ef+2] RES[64] RL[2m] DL[ef+2] (8 B each) + IDS[64] + CTL[16] (4 B each)
     // candidate heap: up to FUSED_CCAP entries, the first `clds` in LDS and the tail in a per-workgroup spill area
@@ -210,10 +211,11 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         HX_HIP(this, hipMalloc((void **)&mr.d_vis, n * 4));
         mr.cap_vis = n;
     }
-    const size_t out_n = mode != 1 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;      // mode 2: k = limit
-    const size_t cnt_n = mode != 1 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
+    // dev: the neighbour lists go straight into the caller's device records (a batch's exchange buffer); only the statuses come back
+    const size_t out_n = dev ? 0 : mode != 1 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;      // mode 2: k = limit
+    const size_t cnt_n = dev ? 0 : mode != 1 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
     // device task/in/out buffers (one allocation, reused)
-    const size_t need = al16((size_t)ntasks * 4) * 3 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
+    const size_t need = al16((size_t)ntasks * 4) * 4 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
     if (need > mr.cap_io) {
         if (mr.d_io) (void)hipFree(mr.d_io);
         if (mr.h_io) (void)hipHostFree(mr.h_io);
@@ -227,6 +229,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t o_ctr = o; o += 256;
     const size_t o_q = o; o += al16((size_t)ntasks * 4);
     const size_t o_lv = o; o += al16((size_t)ntasks * 4);
+    const size_t o_slot = o; o += al16((size_t)ntasks * 4);
     const size_t in_bytes = o;
     const size_t o_st = o; o += al16((size_t)ntasks * 4);
     const size_t o_cnt = o; o += al16(cnt_n * 4);
@@ -236,6 +239,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     memset(mr.h_io + o_ctr, 0, 256);
     memcpy(mr.h_io + o_q, q_sel, (size_t)ntasks * 4);
     if (t_level) memcpy(mr.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(mr.h_io + o_lv, 0, (size_t)ntasks * 4);
+    if (dev && dev->h_slots) memcpy(mr.h_io + o_slot, dev->h_slots, (size_t)ntasks * 4);
     HX_HIP(this, hipMemcpyAsync(mr.d_io, mr.h_io, in_bytes, hipMemcpyHostToDevice, stream));
     FusedParams p;
     p.rows = d_rows; p.queries = d_queries; p.pitch = (uint32_t)pitch; p.nch = (uint32_t)((pitch + 1023) / 1024); p.n_rows = n_rows;
@@ -253,6 +257,12 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     p.n_dist = (unsigned long long *)(mr.d_io + o_ctr + 8);
     p.out_ids = (uint32_t *)(mr.d_io + o_ids); p.out_d = (float *)(mr.d_io + o_d); p.out_cnt = (uint32_t *)(mr.d_io + o_cnt);
     p.status = (uint32_t *)(mr.d_io + o_st);
+    p.o_cst = FUSED_MAXL; p.o_lst = FUSED_MAXL * 2 * mr.m; p.t_oslot = nullptr;
+    if (dev) {   // record = cnt[FUSED_MAXL] | ids[FUSED_MAXL][2m] | d[FUSED_MAXL][2m]  (hx_batch.hip reads the same layout)
+        p.out_cnt = dev->d_rec; p.out_ids = dev->d_rec + FUSED_MAXL; p.out_d = (float *)(dev->d_rec + FUSED_MAXL + FUSED_MAXL * 2 * mr.m);
+        p.o_cst = p.o_lst = dev->rec_words;
+        if (dev->h_slots) p.t_oslot = (const uint32_t *)(mr.d_io + o_slot);
+    }
     if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
     hipError_t ls = hipSuccess;
     ls = dtype == HX_F32 ? hx_launch_fused_f32(this, metric, p, grid, lds, mode)
@@ -260,13 +270,14 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));
-    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, (mode == 2 ? o : o_tix) - o_st, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, (dev ? o_cnt : mode == 2 ? o : o_tix) - o_st, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
     if (roomy == 1 && mode != 2) {   // test hook: pretend every k-th task overflowed, so that the roomy retry path is exercised
         const char *fv = getenv("HX_FORCE_OVERFLOW_MOD"); const uint32_t k = fv ? (uint32_t)atoi(fv) : 0u;
         if (k) for (uint32_t t = 0; t < ntasks; t += k) ((uint32_t *)(mr.h_io + o_st))[t] = FS_OVERFLOW;
     }
-    if (view) {   // the caller reads the pinned staging buffer in place
+    if (dev) { if (status) memcpy(status, mr.h_io + o_st, (size_t)ntasks * 4); }
+    else if (view) {   // the caller reads the pinned staging buffer in place
         view->status = (const uint32_t *)(mr.h_io + o_st); view->cnt = (const uint32_t *)(mr.h_io + o_cnt);
         view->ids = (const uint32_t *)(mr.h_io + o_ids); view->d = (const float *)(mr.h_io + o_d);
     } else {

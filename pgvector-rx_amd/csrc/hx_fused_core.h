@@ -32,6 +32,8 @@ struct FusedParams {
     uint32_t *vis; uint64_t vis_words;            // per-workgroup visited set: open-addressing table of vis_words (power of 2) row ids
     uint32_t *next_task;
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
+    uint32_t o_cst, o_lst;                        // MODE 1 output strides in 32-bit words: out_cnt[s*o_cst + layer], out_ids/out_d[s*o_lst + layer*2m + k] (status[t] stays per task)
+    const uint32_t *t_oslot;                      // MODE 1: output slot s of task t (nullptr: s = t)
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
     // iterative scan (k_fused MODE 2): hnsw.iterative_scan relaxed_order (1) / strict_order (2), scan.rs:794-875
     uint32_t iter_mode, limit; long long max_tuples;

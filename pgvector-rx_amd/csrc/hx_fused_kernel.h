@@ -292,6 +292,9 @@ k_fused(const FusedParams p_in)
         const uint8_t *qsrc = (qsel & HX_QUERY_SLOT) ? p.queries + (size_t)(qsel & 0x7fffffffu) * p.pitch : p.rows + (size_t)qsel * p.pitch;
         f_park(p, qsrc, lane, cx.QV);
         const int new_level = MODE == 1 ? p.t_level[t] : -1;
+        // MODE 1 outputs are addressed through strides so that one launch can fill either the SoA staging arrays or the AoS records
+        // of a batch's exchange buffer (hx_batch.hip); os = output slot of this task
+        const uint32_t os = (MODE == 1 && p.t_oslot) ? p.t_oslot[t] : t;
         if (MODE == 1 && new_level >= FUSED_MAXL) { if (lane == 0) p.status[t] = FS_HOST; continue; }
 
         // d(q, entry point): mod.rs:371-377 / scan.rs:475
@@ -383,7 +386,7 @@ k_fused(const FusedParams p_in)
             if (lane == 0) { p.out_cnt[t] = cnt; p.status[t] = cx.status; }
         } else {
             const int start = new_level < p.entry_level ? new_level : p.entry_level;
-            const size_t obase = (size_t)t * FUSED_MAXL;
+            const size_t obase = (size_t)os * p.o_cst;
             for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
             for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
                 const uint32_t lm = lc == 0 ? lm0 : p.m;
@@ -444,7 +447,7 @@ k_fused(const FusedParams p_in)
                     r = __shfl(r, 0, 64);
                 }
                 __syncthreads();
-                const size_t lb = ((size_t)t * FUSED_MAXL + (size_t)lc) * lm0;
+                const size_t lb = (size_t)os * p.o_lst + (size_t)lc * lm0;
                 for (uint32_t i = lane; i < r; i += 64) { const uint2 v = cx.RL[i]; p.out_ids[lb + i] = v.y; p.out_d[lb + i] = fh_d(v); }
                 if (lane == 0) p.out_cnt[obase + lc] = r;
                 __syncthreads();

@@ -70,67 +70,92 @@ int hx_group_stage(hx_engine *e, uint32_t n_ops, HxGroupWork &w, unsigned long l
     return HX_OK;
 }
 
-// Device arrays of HxGroupWork are (re)allocated here for n_ops ops.  keys/new/d arrive in host memory in op order.
-int hx_group_ops(hx_engine *e, uint32_t n_ops, const unsigned long long *h_keys, const uint32_t *h_new, const float *h_d, uint32_t hub_min,
-                 HxGroupWork &w, uint32_t counters_out[4])
+// Device arrays of HxGroupWork are (re)allocated here for n_ops ops; afterwards w.d_keys / w.d_new / w.d_d are where the ops
+// (op order) must be put -- uploaded by hx_group_ops, or written in place by the batch pipeline's emission kernel (hx_batch.hip).
+namespace {
+struct GroupLayout { size_t kin, kout, iin, iout, nin, din, ns, ds, flag, gid, tg, ly, off, gh, gn, ctr, tmp, total, tmp_bytes; };
+int group_layout(hx_engine *e, uint32_t n_ops, GroupLayout &L)
 {
-    if (n_ops == 0) { counters_out[0] = counters_out[1] = counters_out[2] = counters_out[3] = 0; return HX_OK; }
-    HX_HIP(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
     size_t tmp_sort = 0, tmp_scan = 0;
     HX_HIP(e, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_ops, 0, 39, st));
     HX_HIP(e, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_ops, st));
-    const size_t tmp_bytes = std::max(tmp_sort, tmp_scan);
+    L.tmp_bytes = std::max(tmp_sort, tmp_scan);
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t n = n_ops;
     size_t o = 0;
-    const size_t o_kin = o; o += al(n * 8); const size_t o_kout = o; o += al(n * 8);
-    const size_t o_iin = o; o += al(n * 4); const size_t o_iout = o; o += al(n * 4);
-    const size_t o_nin = o; o += al(n * 4); const size_t o_din = o; o += al(n * 4);
-    const size_t o_ns = o; o += al(n * 4); const size_t o_ds = o; o += al(n * 4);
-    const size_t o_flag = o; o += al(n * 4); const size_t o_gid = o; o += al(n * 4);
-    const size_t o_tg = o; o += al(n * 4); const size_t o_ly = o; o += al(n * 4); const size_t o_off = o; o += al((n + 1) * 4);
-    const size_t o_gh = o; o += al(n * 4); const size_t o_gn = o; o += al(n * 4);
-    const size_t o_ctr = o; o += 256;
-    const size_t o_tmp = o; o += al(tmp_bytes);
-    if (o > w.cap) {
+    L.kin = o; o += al(n * 8); L.kout = o; o += al(n * 8);
+    L.iin = o; o += al(n * 4); L.iout = o; o += al(n * 4);
+    L.nin = o; o += al(n * 4); L.din = o; o += al(n * 4);
+    L.ns = o; o += al(n * 4); L.ds = o; o += al(n * 4);
+    L.flag = o; o += al(n * 4); L.gid = o; o += al(n * 4);
+    L.tg = o; o += al(n * 4); L.ly = o; o += al(n * 4); L.off = o; o += al((n + 1) * 4);
+    L.gh = o; o += al(n * 4); L.gn = o; o += al(n * 4);
+    L.ctr = o; o += 256;
+    L.tmp = o; o += al(L.tmp_bytes);
+    L.total = o;
+    return HX_OK;
+}
+}  // namespace
+
+int hx_group_reserve(hx_engine *e, uint32_t n_ops, HxGroupWork &w)
+{
+    HX_HIP(e, hipSetDevice(e->device));
+    GroupLayout L; int rc = group_layout(e, n_ops ? n_ops : 1, L); if (rc) return rc;
+    if (L.total > w.cap) {
+        HX_HIP(e, hipStreamSynchronize(e->stream));
         if (w.d) (void)hipFree(w.d);
         w.d = nullptr; w.cap = 0;
-        HX_HIP(e, hipMalloc((void **)&w.d, o * 2));
-        w.cap = o * 2;
+        HX_HIP(e, hipMalloc((void **)&w.d, L.total * 2));
+        w.cap = L.total * 2;
     }
     if (!w.h_ctr) HX_HIP(e, hipHostMalloc((void **)&w.h_ctr, 64, hipHostMallocDefault));
-    uint8_t *b = w.d;
-    static const bool dbg = getenv("HX_DEBUG") != nullptr; static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = dbg ? now() : 0.0;
-    HX_HIP(e, hipMemcpyAsync(b + o_kin, h_keys, n * 8, hipMemcpyHostToDevice, st));
-    HX_HIP(e, hipMemcpyAsync(b + o_nin, h_new, n * 4, hipMemcpyHostToDevice, st));
-    HX_HIP(e, hipMemcpyAsync(b + o_din, h_d, n * 4, hipMemcpyHostToDevice, st));
-    HX_HIP(e, hipMemsetAsync(b + o_ctr, 0, 256, st));
-    const uint32_t tb = 256, gb = (n_ops + tb - 1) / tb;
-    if (dbg) { (void)hipStreamSynchronize(st); const double t = now(); acc[0] += t - t0; t0 = t; }
-    hipLaunchKernelGGL(k_iota, dim3(gb), dim3(tb), 0, st, (uint32_t *)(b + o_iin), n_ops);
-    size_t tb_sort = tmp_bytes;
-    HX_HIP(e, hipcub::DeviceRadixSort::SortPairs(b + o_tmp, tb_sort, (const unsigned long long *)(b + o_kin), (unsigned long long *)(b + o_kout),
-                                                 (const uint32_t *)(b + o_iin), (uint32_t *)(b + o_iout), (int)n_ops, 0, 39, st));
-    if (dbg) { (void)hipStreamSynchronize(st); const double t = now(); acc[1] += t - t0; t0 = t; }
-    hipLaunchKernelGGL(k_flags, dim3(gb), dim3(tb), 0, st, (const unsigned long long *)(b + o_kout), (const uint32_t *)(b + o_iout),
-                       (const uint32_t *)(b + o_nin), (const float *)(b + o_din), (uint32_t *)(b + o_ns), (float *)(b + o_ds), (uint32_t *)(b + o_flag), n_ops);
-    size_t tb_scan = tmp_bytes;
-    HX_HIP(e, hipcub::DeviceScan::ExclusiveSum(b + o_tmp, tb_scan, (const uint32_t *)(b + o_flag), (uint32_t *)(b + o_gid), (int)n_ops, st));
-    hipLaunchKernelGGL(k_groups, dim3(gb), dim3(tb), 0, st, (const unsigned long long *)(b + o_kout), (const uint32_t *)(b + o_flag), (const uint32_t *)(b + o_gid),
-                       (uint32_t *)(b + o_tg), (uint32_t *)(b + o_ly), (uint32_t *)(b + o_off), n_ops, (uint32_t *)(b + o_ctr));
-    hipLaunchKernelGGL(k_split, dim3(gb), dim3(tb), 0, st, (const uint32_t *)(b + o_off), (const uint32_t *)(b + o_ctr), hub_min,
-                       (uint32_t *)(b + o_gh), (uint32_t *)(b + o_gn), (uint32_t *)(b + o_ctr));
-    HX_HIP(e, hipGetLastError());
-    HX_HIP(e, hipMemcpyAsync(w.h_ctr, b + o_ctr, 16, hipMemcpyDeviceToHost, st));
-    HX_HIP(e, hipStreamSynchronize(st));
-    if (dbg) { const double t = now(); acc[2] += t - t0; if (++calls % 50 == 0) fprintf(stderr, "[hx] hx_group_ops x%d: upload %.1f ms, iota+sort %.1f ms, flags+scan+groups+split+readback %.1f ms (n_ops %u)\n", calls, acc[0] * 1e3, acc[1] * 1e3, acc[2] * 1e3, n_ops); }
-    for (int i = 0; i < 4; i++) counters_out[i] = w.h_ctr[i];
-    w.tg = (const uint32_t *)(b + o_tg); w.ly = (const uint32_t *)(b + o_ly); w.off = (const uint32_t *)(b + o_off);
-    w.op_new = (const uint32_t *)(b + o_ns); w.op_d = (const float *)(b + o_ds);
-    w.gmap_hub = (const uint32_t *)(b + o_gh); w.gmap_norm = (const uint32_t *)(b + o_gn);
+    w.d_keys = (unsigned long long *)(w.d + L.kin); w.d_new = (uint32_t *)(w.d + L.nin); w.d_d = (float *)(w.d + L.din);
     return HX_OK;
+}
+
+// groups the n_ops ops already present in w.d_keys / w.d_new / w.d_d (hx_group_reserve(n_ops) placed those arrays)
+int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w, uint32_t counters_out[4])
+{
+    if (n_ops == 0) { counters_out[0] = counters_out[1] = counters_out[2] = counters_out[3] = 0; return HX_OK; }
+    HX_HIP(e, hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    GroupLayout L; int rc = group_layout(e, n_ops, L); if (rc) return rc;
+    if (L.total > w.cap || !w.d) return e->fail(HX_E_STATE, "hx_group_run without hx_group_reserve");
+    uint8_t *b = w.d;
+    HX_HIP(e, hipMemsetAsync(b + L.ctr, 0, 256, st));
+    const uint32_t tb = 256, gb = (n_ops + tb - 1) / tb;
+    hipLaunchKernelGGL(k_iota, dim3(gb), dim3(tb), 0, st, (uint32_t *)(b + L.iin), n_ops);
+    size_t tb_sort = L.tmp_bytes;
+    HX_HIP(e, hipcub::DeviceRadixSort::SortPairs(b + L.tmp, tb_sort, (const unsigned long long *)(b + L.kin), (unsigned long long *)(b + L.kout),
+                                                 (const uint32_t *)(b + L.iin), (uint32_t *)(b + L.iout), (int)n_ops, 0, 39, st));
+    hipLaunchKernelGGL(k_flags, dim3(gb), dim3(tb), 0, st, (const unsigned long long *)(b + L.kout), (const uint32_t *)(b + L.iout),
+                       (const uint32_t *)(b + L.nin), (const float *)(b + L.din), (uint32_t *)(b + L.ns), (float *)(b + L.ds), (uint32_t *)(b + L.flag), n_ops);
+    size_t tb_scan = L.tmp_bytes;
+    HX_HIP(e, hipcub::DeviceScan::ExclusiveSum(b + L.tmp, tb_scan, (const uint32_t *)(b + L.flag), (uint32_t *)(b + L.gid), (int)n_ops, st));
+    hipLaunchKernelGGL(k_groups, dim3(gb), dim3(tb), 0, st, (const unsigned long long *)(b + L.kout), (const uint32_t *)(b + L.flag), (const uint32_t *)(b + L.gid),
+                       (uint32_t *)(b + L.tg), (uint32_t *)(b + L.ly), (uint32_t *)(b + L.off), n_ops, (uint32_t *)(b + L.ctr));
+    hipLaunchKernelGGL(k_split, dim3(gb), dim3(tb), 0, st, (const uint32_t *)(b + L.off), (const uint32_t *)(b + L.ctr), hub_min,
+                       (uint32_t *)(b + L.gh), (uint32_t *)(b + L.gn), (uint32_t *)(b + L.ctr));
+    HX_HIP(e, hipGetLastError());
+    HX_HIP(e, hipMemcpyAsync(w.h_ctr, b + L.ctr, 16, hipMemcpyDeviceToHost, st));
+    HX_HIP(e, hipStreamSynchronize(st));
+    for (int i = 0; i < 4; i++) counters_out[i] = w.h_ctr[i];
+    w.tg = (const uint32_t *)(b + L.tg); w.ly = (const uint32_t *)(b + L.ly); w.off = (const uint32_t *)(b + L.off);
+    w.op_new = (const uint32_t *)(b + L.ns); w.op_d = (const float *)(b + L.ds);
+    w.gmap_hub = (const uint32_t *)(b + L.gh); w.gmap_norm = (const uint32_t *)(b + L.gn);
+    return HX_OK;
+}
+
+// keys / new ids / distances arrive in host memory (op order)
+int hx_group_ops(hx_engine *e, uint32_t n_ops, const unsigned long long *h_keys, const uint32_t *h_new, const float *h_d, uint32_t hub_min,
+                 HxGroupWork &w, uint32_t counters_out[4])
+{
+    if (n_ops == 0) { counters_out[0] = counters_out[1] = counters_out[2] = counters_out[3] = 0; return HX_OK; }
+    int rc = hx_group_reserve(e, n_ops, w); if (rc) return rc;
+    HX_HIP(e, hipMemcpyAsync(w.d_keys, h_keys, (size_t)n_ops * 8, hipMemcpyHostToDevice, e->stream));
+    HX_HIP(e, hipMemcpyAsync(w.d_new, h_new, (size_t)n_ops * 4, hipMemcpyHostToDevice, e->stream));
+    HX_HIP(e, hipMemcpyAsync(w.d_d, h_d, (size_t)n_ops * 4, hipMemcpyHostToDevice, e->stream));
+    return hx_group_run(e, n_ops, hub_min, w, counters_out);
 }

@@ -550,6 +550,8 @@ struct Pool {
 struct BatchState {
     bool open = false, linked = false;
     bool lazy_lists = false;     // single-process insert: lists pruned on the device are not copied back per batch (hx_index::ensure_host_lists)
+    bool merged = false;         // merge_duplicates ran (rollback undoes its TID merges)
+    bool dev = false;            // device-resident batch (hx_index_dbatch_*): the members' lists never visit the host
     uint32_t base = 0, b = 0, entry = 0; int entry_level = 0;
     std::vector<int64_t> tids; std::vector<uint32_t> elem; std::vector<uint8_t> searched;
     std::vector<BackOp> ops; std::vector<std::pair<size_t, size_t>> grp;
@@ -573,6 +575,8 @@ struct hx_index {
     int fail(int code, const std::string &m) { err = m; return code; }
 
     bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192; }
+    // device-resident batches (hx_batch.hip): the traversal kernel and the back-link kernels both serve this m
+    bool dbatch_ok() const { static const bool off = getenv("HX_DEVICE_BATCH") && atoi(getenv("HX_DEVICE_BATCH")) == 0; return !off && fused_ok() && 2 * g.m <= 32; }
     void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
     // brings the device copy of the graph up to date: levels of new elements + every list written since the last sync
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -615,7 +619,65 @@ struct hx_index {
     // scratch of hx_index_batch_links, kept between batches (a batch allocates and page-faults ~10 MB otherwise)
     struct LinkScratch { std::vector<BackOp> raw; std::vector<uint32_t> hist, own, tg, ly, off, onew, opstart, da, db, dstart; std::vector<float> od; std::vector<uint8_t> deq;
                          std::vector<unsigned long long> keys;
+                         std::vector<uint32_t> za, zb, ha, hb, cls; std::vector<int32_t> cur; std::vector<uint8_t> dupflag;
                          std::vector<std::vector<std::pair<size_t, size_t>>> bgrp; } ls;
+    // build.rs:482-525 for the open batch, in row order: a member merges into the first byte-identical zero-distance layer-0 neighbour that
+    // has room for another heap TID ((za, zb): confirmed (member, neighbour) pairs in list order), else into the earliest identical member of
+    // this batch that is still an element of its own and has room ((ha, hb): confirmed (later, earlier) pairs, ascending); otherwise it stays
+    // an element and may become the entry point.  A merged member is tombstoned (level -1 - level); ls.dupflag marks them.  Returns their number.
+    uint32_t merge_duplicates(const std::vector<uint32_t> &za, const std::vector<uint32_t> &zb, const std::vector<uint32_t> &ha, const std::vector<uint32_t> &hb)
+    {
+        const uint32_t b = bs.b, base = bs.base;
+        auto &cls = ls.cls; auto &cur = ls.cur; auto &dupflag = ls.dupflag;
+        dupflag.assign(b, 0);
+        const bool classes = !ha.empty();
+        if (classes) {
+            cls.resize(b); cur.assign(b, -1);
+            for (uint32_t i = 0; i < b; i++) cls[i] = i;
+            for (size_t k = 0; k < ha.size(); k++) cls[ha[k] - base] = cls[hb[k] - base];      // ascending in ha: the earlier member's class is final
+        }
+        size_t zp = 0; uint32_t n_dup = 0;
+        bs.merged = true;
+        for (uint32_t i = 0; i < b; i++) {
+            const uint32_t id = base + i;
+            int64_t dup = -1;
+            while (zp < za.size() && za[zp] < id) zp++;
+            for (size_t k = zp; k < za.size() && za[k] == id; k++)
+                if (g.ntids[zb[k]] < HEAPTIDS && g.level[zb[k]] >= 0) { dup = zb[k]; break; }
+            if (dup < 0 && classes) { const int32_t c = cur[cls[i]]; if (c >= 0 && g.ntids[base + (uint32_t)c] < HEAPTIDS) dup = base + (uint32_t)c; }
+            if (dup >= 0) {                                     // merge into the existing element; this row becomes a tombstone
+                g.tids[dup][g.ntids[dup]++] = bs.tids[i];
+                g.level[id] = -1 - g.level[id];
+                bs.elem[i] = (uint32_t)dup; dupflag[i] = 1; n_dup++;
+            } else {
+                if (g.level[id] > g.level[g.entry]) g.entry = id;   // build.rs:523-525
+                g.tids[id][0] = bs.tids[i]; g.ntids[id] = 1;
+                bs.elem[i] = id;
+                if (classes) cur[cls[i]] = (int32_t)i;
+            }
+        }
+        return n_dup;
+    }
+    // a stage of the open batch failed: the elements batch_begin added hold no lists or TIDs and must not stay in the graph, or the rows
+    // could never be inserted again (first_row != index size); dropped here, together with the entry point / TIDs the batch had not touched yet
+    void rollback_batch()
+    {
+        if (bs.open) {
+            const uint32_t keep = bs.base;
+            if (!bs.linked && bs.merged) {                       // TIDs merged into older elements, entry point moved to a member
+                for (uint32_t i = bs.b; i-- > 0;) if (ls.dupflag[i] && bs.elem[i] < keep && g.ntids[bs.elem[i]] > 0) g.ntids[bs.elem[i]]--;
+                g.entry = bs.entry;
+            }
+            if (!bs.linked && g.size() > keep) {
+                g.level.resize(keep); g.n0_cnt.resize(keep); g.n0.resize((size_t)keep * 2 * g.m);
+                g.up.resize(g.up_off[keep]); g.up_cnt.resize(g.upc_off[keep]); g.up_off.resize(keep); g.upc_off.resize(keep);
+                g.tids.resize(keep); g.ntids.resize(keep);
+                if (mirror_elems > keep) mirror_elems = keep;
+                size_t w = 0; for (size_t k = 0; k < dirty.size(); k++) if (dirty[k].first < keep) dirty[w++] = dirty[k]; dirty.resize(w);
+            }
+        }
+        bs = BatchState();
+    }
     int ensure_host_lists()
     {
         if (!host_stale) return HX_OK;
@@ -925,34 +987,27 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
     const uint32_t b = bs.b, base = bs.base;
     int rc;
     double t_links0 = hx_index::now_s();
-    // duplicate detection (build.rs:482-512): byte-compare the leading zero-distance layer-0 neighbours
-    auto &da = ix->ls.da; auto &db = ix->ls.db; auto &dstart = ix->ls.dstart; da.clear(); db.clear(); dstart.assign(b + 1, 0u);
+    // duplicate detection (build.rs:482-512): byte-compare the leading zero-distance layer-0 neighbours; rows that are identical to
+    // an EARLIER member of this batch are found by hashing on the device (they are not linked yet, so the graph cannot show them)
+    auto &da = ix->ls.da; auto &db = ix->ls.db; da.clear(); db.clear();
     for (uint32_t i = 0; i < b; i++) {
         const uint32_t id = base + i; const Cand *l0 = g.list(id, 0);
         for (uint16_t k = 0; k < g.cnt(id, 0); k++) { if (l0[k].d != 0.0f) break; da.push_back(id); db.push_back(l0[k].id); }
-        dstart[i + 1] = (uint32_t)da.size();
     }
     auto &deq = ix->ls.deq; deq.assign(da.size(), 0);
     if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
+    auto &za = ix->ls.za; auto &zb = ix->ls.zb; auto &ha = ix->ls.ha; auto &hb = ix->ls.hb;
+    if ((rc = ix->e->db_dup_candidates(base, b, nullptr, za, zb, ha, hb))) return ix->fail(rc, ix->e->err);
+    za.clear(); zb.clear();
+    for (size_t k = 0; k < da.size(); k++) if (deq[k]) { za.push_back(da[k]); zb.push_back(db[k]); }
+    ix->merge_duplicates(za, zb, ha, hb);
     std::vector<BackOp> &ops = bs.ops; ops.clear();
     auto &opstart = ix->ls.opstart; opstart.assign(b + 1, 0u);   // ops of member i land at [opstart[i], opstart[i+1])
     for (uint32_t i = 0; i < b; i++) {
         const uint32_t id = base + i;
-        int64_t dup = -1;
-        for (uint32_t k = dstart[i]; k < dstart[i + 1]; k++)
-            if (deq[k] && g.ntids[db[k]] < HEAPTIDS && g.level[db[k]] >= 0) { dup = db[k]; break; }
         uint32_t nops = 0;
-        if (dup >= 0) {                                     // merge into the existing element; this row becomes a tombstone
-            g.tids[dup][g.ntids[dup]++] = bs.tids[i];
-            for (int lc = 0; lc <= g.level[id]; lc++) g.cnt(id, lc) = 0;
-            g.level[id] = -1 - g.level[id];
-            bs.elem[i] = (uint32_t)dup;
-        } else {
-            for (int lc = g.level[id]; lc >= 0; lc--) nops += g.cnt(id, lc);
-            if (g.level[id] > g.level[g.entry]) g.entry = id;   // build.rs:523-525
-            g.tids[id][0] = bs.tids[i]; g.ntids[id] = 1;
-            bs.elem[i] = id;
-        }
+        if (g.level[id] < 0) { const int lv = -1 - g.level[id]; for (int lc = 0; lc <= lv; lc++) g.cnt(id, lc) = 0; }   // tombstone: no links
+        else for (int lc = g.level[id]; lc >= 0; lc--) nops += g.cnt(id, lc);
         opstart[i + 1] = opstart[i] + nops;
     }
     // Single-process build on the device path: the ops are only listed here (update_neighbor_connections order, mod.rs:451-458);
@@ -1155,6 +1210,179 @@ int hx_index_batch_end(hx_index *ix, uint32_t *elem_out)
     return HX_OK;
 }
 
+
+// ================================================================================================
+// Device-resident batches (hx_batch.hip): the same batch as hx_index_batch_*, but the members' neighbour lists stay in device
+// records from k_fused<insert> to the back-link kernels; the host only sees statuses, duplicate candidates and counters.
+// hx_index_insert runs begin, search(0, b), links(0, 1), end on an engine-owned record buffer; a multi-GPU build passes its
+// exchange buffers (pgvector-rx_amd/dist_build.py) and all-gathers them between the stages.
+// ================================================================================================
+int hx_index_dbatch_supported(const hx_index *ix, const int32_t *levels, uint32_t b)
+{
+    if (!ix || !levels || !ix->dbatch_ok() || ix->g.entry < 0) return 0;
+    const int mxl = max_level_for(ix->g.m);
+    for (uint32_t i = 0; i < b; i++) if (std::min(levels[i], mxl) >= HX_FUSED_MAXL) return 0;   // a member above the kernel's layers: host path for this batch
+    return 1;
+}
+uint64_t hx_index_dbatch_record_bytes(const hx_index *ix) { return ix ? (uint64_t)hx_rec_words((uint32_t)ix->g.m) * 4 : 0; }
+uint64_t hx_index_dbatch_list_record_bytes(const hx_index *ix) { return ix ? (uint64_t)hx_xrec_words((uint32_t)ix->g.m) * 4 : 0; }
+
+int hx_index_dbatch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids)
+{
+    if (!ix) return HX_E_ARG;
+    hx_index::Timer t_bb(ix->prof[12]);
+    if (b == 0 || !levels || !tids) return ix->fail(HX_E_ARG, "empty batch or NULL argument");
+    Graph &g = ix->g; BatchState &bs = ix->bs;
+    if (bs.open) return ix->fail(HX_E_STATE, "a batch is already open");
+    if (!hx_index_dbatch_supported(ix, levels, b)) return ix->fail(HX_E_STATE, "this batch cannot run device-resident (hx_index_dbatch_supported)");
+    if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
+    if (first_row + b > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
+    const int mxl = max_level_for(g.m);
+    {   // keep the vectors' capacity from batch to batch
+        BatchState fresh;
+        fresh.tids.swap(bs.tids); fresh.elem.swap(bs.elem); fresh.searched.swap(bs.searched); fresh.ops.swap(bs.ops); fresh.grp.swap(bs.grp);
+        fresh.tids.clear(); fresh.elem.clear(); fresh.searched.clear(); fresh.ops.clear(); fresh.grp.clear();
+        bs = std::move(fresh);
+    }
+    bs.open = true; bs.dev = true; bs.base = g.size(); bs.b = b; bs.entry = (uint32_t)g.entry; bs.entry_level = g.level[g.entry];
+    bs.tids.assign(tids, tids + b); bs.elem.assign(b, 0); bs.searched.assign(b, 0);
+    for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[i], mxl); if (lv < 0) lv = 0; g.add(lv); }
+    // levels / upper-layer blocks of the new elements and every list the host wrote since the last launch go to the mirror now;
+    // from here on the mirror is the only place this batch's lists exist
+    int rc = ix->sync_mirror();
+    if (rc) { ix->rollback_batch(); return rc; }
+    return HX_OK;
+}
+
+// find_element_neighbors for members [lo, hi); their records are written at d_records + (member - lo) * record_bytes
+int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_records)
+{
+    if (!ix) return HX_E_ARG;
+    hx_index::Timer t_bs(ix->prof[11]);
+    BatchState &bs = ix->bs; Graph &g = ix->g;
+    if (!bs.open || !bs.dev || lo > hi || hi > bs.b) return ix->fail(HX_E_STATE, "no open device batch / bad member range");
+    if (hi == lo) return HX_OK;
+    if (!d_records) return ix->fail(HX_E_ARG, "d_records is NULL");
+    const uint32_t n = hi - lo, rw = hx_rec_words((uint32_t)g.m);
+    std::vector<uint32_t> qsel(n), status(n); std::vector<int32_t> tl(n);
+    for (uint32_t i = 0; i < n; i++) { qsel[i] = bs.base + lo + i; tl[i] = g.level[bs.base + lo + i]; }
+    uint64_t cnts[2] = {0, 0};
+    HxFusedDev dev; dev.d_rec = (uint32_t *)d_records; dev.rec_words = rw;
+    int rc;
+    const double t0 = hx_index::now_s();
+    if ((rc = ix->e->fused_run(1, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
+                               nullptr, nullptr, nullptr, status.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, ix->e->err);
+    ix->prof[6] += hx_index::now_s() - t0;
+    ix->counters[1] += cnts[0]; ix->counters[2] += cnts[1];
+    std::vector<uint32_t> again, todo;
+    for (uint32_t i = 0; i < n; i++) { if (status[i] == 0) bs.searched[lo + i] = 1; else if (status[i] == 1) again.push_back(i); else todo.push_back(i); }
+    if (!again.empty()) {                                        // overflowed tables: one more try on the device with roomier ones
+        const uint32_t na = (uint32_t)again.size();
+        std::vector<uint32_t> q2(na), st2(na); std::vector<int32_t> l2(na);
+        for (uint32_t k = 0; k < na; k++) { q2[k] = bs.base + lo + again[k]; l2[k] = g.level[bs.base + lo + again[k]]; }
+        HxFusedDev dev2 = dev; dev2.h_slots = again.data();
+        if ((rc = ix->e->fused_run(1, na, q2.data(), l2.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
+                                   nullptr, nullptr, nullptr, st2.data(), cnts, nullptr, nullptr, 8, &dev2))) return ix->fail(rc, ix->e->err);
+        ix->counters[1] += cnts[0]; ix->counters[2] += cnts[1];
+        for (uint32_t k = 0; k < na; k++) { if (st2[k] == 0) bs.searched[lo + again[k]] = 1; else todo.push_back(again[k]); }
+    }
+    ix->fused_tasks += n; ix->fused_redo += todo.size();
+    if (todo.empty()) return HX_OK;
+    // still overflowing: the lock-step driver on the host copy of the graph as of the batch start (the mirror holds exactly that)
+    ix->host_stale = true;
+    std::vector<std::unique_ptr<InsertTask>> &its = ix->insert_pool;
+    while (its.size() < todo.size()) its.emplace_back(new InsertTask());
+    std::vector<LsTask *> tasks(todo.size());
+    for (size_t ti = 0; ti < todo.size(); ti++) {
+        InsertTask &t = *its[ti];
+        t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
+        t.g = &g; t.id = bs.base + lo + todo[ti]; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
+        tasks[ti] = &t;
+    }
+    if ((rc = ix->run_lockstep(tasks))) return rc;
+    const uint32_t lm0 = 2u * (uint32_t)g.m;
+    std::vector<uint32_t> src(HX_FUSED_MAXL + 2u * HX_FUSED_MAXL * lm0);
+    for (size_t ti = 0; ti < todo.size(); ti++) {
+        InsertTask &t = *its[ti];
+        std::fill(src.begin(), src.end(), 0u);
+        for (int lc = 0; lc <= t.new_level; lc++) {
+            src[lc] = (uint32_t)t.nb[lc].size();
+            for (size_t k = 0; k < t.nb[lc].size(); k++) {
+                src[HX_FUSED_MAXL + (size_t)lc * lm0 + k] = t.nb[lc][k].id;
+                memcpy(&src[HX_FUSED_MAXL + HX_FUSED_MAXL * lm0 + (size_t)lc * lm0 + k], &t.nb[lc][k].d, 4);
+            }
+        }
+        if ((rc = ix->e->db_fill_record((uint32_t *)d_records, todo[ti], src.data()))) return ix->fail(rc, ix->e->err);
+        ix->counters[1] += t.n_dist; ix->counters[2] += t.n_pair;
+        bs.searched[lo + todo[ti]] = 1;
+    }
+    return HX_OK;
+}
+
+// every rank: duplicate merge + entry point + the members' lists into the mirror; then update_neighbor_connections for the lists this rank owns.
+// d_records holds ALL b member records (record i = member i).  *n_list_records = lists this rank pruned (their records: export_links).
+int hx_index_dbatch_links(hx_index *ix, uint32_t rank, uint32_t world, const void *d_records, uint64_t *n_list_records)
+{
+    if (!ix) return HX_E_ARG;
+    BatchState &bs = ix->bs;
+    if (n_list_records) *n_list_records = 0;
+    if (!bs.open || !bs.dev || world == 0 || rank >= world || !d_records) return ix->fail(HX_E_STATE, "no open device batch / bad rank");
+    const uint32_t b = bs.b, base = bs.base;
+    const double t0 = hx_index::now_s();
+    int rc;
+    auto &za = ix->ls.za; auto &zb = ix->ls.zb; auto &ha = ix->ls.ha; auto &hb = ix->ls.hb;
+    if ((rc = ix->e->db_dup_candidates(base, b, (const uint32_t *)d_records, za, zb, ha, hb))) return ix->fail(rc, ix->e->err);
+    const uint32_t n_dup = ix->merge_duplicates(za, zb, ha, hb);
+    uint32_t n_ops = 0;
+    if ((rc = ix->e->db_apply(base, b, (const uint32_t *)d_records, n_dup ? ix->ls.dupflag.data() : nullptr, rank, world, &n_ops))) return ix->fail(rc, ix->e->err);
+    ix->prof[8] += hx_index::now_s() - t0;
+    {
+        hx_index::Timer tl(ix->prof[9]);
+        uint64_t np = 0; uint32_t st[2] = {0, 0};
+        if ((rc = ix->e->links_run_grouped(n_ops, nullptr, nullptr, nullptr, &np, st, true, world > 1))) return ix->fail(rc, ix->e->err);
+        ix->counters[3] += np;
+        ix->prof[13] = std::max(ix->prof[13], (double)st[1]); ix->prof[14] += n_ops;
+    }
+    ix->host_stale = true;
+    bs.linked = true;
+    if (n_list_records) *n_list_records = world > 1 ? ix->e->xl_records : 0;
+    return HX_OK;
+}
+
+int hx_index_dbatch_export_links(hx_index *ix, void *d_out)
+{
+    if (!ix || !ix->bs.open || !ix->bs.dev || !ix->bs.linked) return HX_E_ARG;
+    hx_engine *e = ix->e;
+    if (e->xl_records == 0) return HX_OK;
+    if (!d_out) return ix->fail(HX_E_ARG, "d_out is NULL");
+    const size_t bytes = (size_t)e->xl_records * hx_xrec_words((uint32_t)ix->g.m) * 4;
+    if (hipMemcpyAsync(d_out, e->d_xl, bytes, hipMemcpyDeviceToDevice, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+        return ix->fail(HX_E_HIP, "export of the pruned-list records failed");
+    return HX_OK;
+}
+
+int hx_index_dbatch_import_links(hx_index *ix, const void *d_list_records, uint64_t n)
+{
+    if (!ix || !ix->bs.open || !ix->bs.dev || !ix->bs.linked) return HX_E_ARG;
+    if (n == 0) return HX_OK;
+    if (!d_list_records || n > 0xFFFFFFFFull) return ix->fail(HX_E_ARG, "bad list records");
+    int rc = ix->e->db_import_lists((const uint32_t *)d_list_records, (uint32_t)n);
+    if (rc) return ix->fail(rc, ix->e->err);
+    ix->host_stale = true;
+    return HX_OK;
+}
+
+int hx_index_dbatch_end(hx_index *ix, uint32_t *elem_out)
+{
+    if (!ix) return HX_E_ARG;
+    BatchState &bs = ix->bs;
+    if (!bs.open || !bs.dev || !bs.linked) return ix->fail(HX_E_STATE, "device batch not linked yet");
+    if (hipStreamSynchronize(ix->e->stream) != hipSuccess) return ix->fail(HX_E_HIP, "stream synchronisation failed");   // imports have landed before the caller reuses its buffers
+    if (elem_out) memcpy(elem_out, bs.elem.data(), (size_t)bs.b * sizeof(uint32_t));
+    bs.open = false; bs.linked = false; bs.dev = false; bs.lazy_lists = false; bs.b = 0;
+    return HX_OK;
+}
+
 int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids,
                     uint32_t batch, uint32_t *elem_out)
 {
@@ -1186,13 +1414,22 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
             if (b == 0) continue;
         }
         int rc;
+        if (hx_index_dbatch_supported(ix, levels + done, b)) {
+            // device-resident batch: lists go from k_fused<insert> to the back-link kernels without visiting the host
+            if ((rc = ix->e->db_reserve_records(b))) return ix->fail(rc, ix->e->err);
+            if ((rc = hx_index_dbatch_begin(ix, first_row + done, b, levels + done, tids + done))) return rc;
+            if ((rc = hx_index_dbatch_search(ix, 0, b, ix->e->bw.d_rec)) || (rc = hx_index_dbatch_links(ix, 0, 1, ix->e->bw.d_rec, nullptr)) ||
+                (rc = hx_index_dbatch_end(ix, elem_out ? elem_out + done : nullptr))) { ix->rollback_batch(); return rc; }
+            done += b;
+            continue;
+        }
         ix->in_insert = true;
         rc = hx_index_batch_begin(ix, first_row + done, b, levels + done, tids + done);
         ix->in_insert = false;
         if (rc) return rc;
         ix->bs.lazy_lists = true;
         if ((rc = hx_index_batch_search(ix, 0, b)) || (rc = hx_index_batch_links(ix, 0, 1)) ||
-            (rc = hx_index_batch_end(ix, elem_out ? elem_out + done : nullptr))) { ix->bs = BatchState(); return rc; }
+            (rc = hx_index_batch_end(ix, elem_out ? elem_out + done : nullptr))) { ix->rollback_batch(); return rc; }
         done += b;
     }
     return HX_OK;

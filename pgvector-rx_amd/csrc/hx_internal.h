@@ -56,13 +56,28 @@ struct HxMirror {
 // zero-copy view of a fused_run's results in the engine's pinned staging buffer (valid until the next fused_run)
 struct HxFusedView { const uint32_t *ids = nullptr, *cnt = nullptr, *status = nullptr; const float *d = nullptr; };
 
+// insert-mode results written straight into device records (a batch's exchange buffer, hx_batch.hip): record r =
+// cnt[HX_FUSED_MAXL] | ids[HX_FUSED_MAXL][2m] | d[HX_FUSED_MAXL][2m], rec_words 32-bit words apart; task t fills record h_slots[t] (nullptr: t)
+struct HxFusedDev { uint32_t *d_rec = nullptr; uint32_t rec_words = 0; const uint32_t *h_slots = nullptr; };
+
 // device-side grouping of a batch's back-link ops (hx_group.hip): workspace + the grouped arrays it leaves on the device
 struct HxGroupWork {
     uint8_t *d = nullptr; size_t cap = 0; uint32_t *h_ctr = nullptr; uint8_t *h = nullptr; size_t cap_h = 0;   // device workspace, pinned counters, pinned op staging
     const uint32_t *tg = nullptr, *ly = nullptr, *off = nullptr, *op_new = nullptr, *gmap_hub = nullptr, *gmap_norm = nullptr; const float *op_d = nullptr;
+    unsigned long long *d_keys = nullptr; uint32_t *d_new = nullptr; float *d_d = nullptr;   // where the ungrouped ops go (after hx_group_reserve)
 };
+// workspace of the device-resident batch pipeline (hx_batch.hip)
+struct HxBatchWork {
+    uint8_t *d = nullptr; size_t cap = 0;               // device scratch (hashes, candidate pairs, op counts)
+    uint8_t *h = nullptr; size_t cap_h = 0; uint32_t *h_ctr = nullptr;   // pinned staging and counters
+    uint32_t *d_rec = nullptr; size_t cap_rec = 0;      // member records of single-process batches (multi-GPU builds pass their exchange buffer instead)
+};
+uint32_t hx_rec_words(uint32_t m);                      // 32-bit words per member record: cnt[HX_FUSED_MAXL] | ids[HX_FUSED_MAXL][2m] | d[HX_FUSED_MAXL][2m]
 struct hx_engine;
+static inline uint32_t hx_xrec_words(uint32_t m) { return (3u + 4u * m + 3u) & ~3u; }   // list record of the multi-GPU exchange: target, layer, cnt, ids[2m], d[2m]
 int hx_group_stage(hx_engine *e, uint32_t n_ops, HxGroupWork &w, unsigned long long **keys, uint32_t **op_new, float **op_d);
+int hx_group_reserve(hx_engine *e, uint32_t n_ops, HxGroupWork &w);
+int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w, uint32_t counters_out[4]);
 int hx_group_ops(hx_engine *e, uint32_t n_ops, const unsigned long long *h_keys, const uint32_t *h_new, const float *h_d, uint32_t hub_min,
                  HxGroupWork &w, uint32_t counters_out[4]);   // counters: groups, hub lists, other lists, longest chain
 
@@ -103,14 +118,26 @@ struct hx_engine {
     // update_neighbor_connections for a batch whose ops (key = target << 7 | layer, new element, distance; op order) are grouped on the device;
     // the updated lists stay in the mirror.  stats: [0] groups, [1] longest chain
     int links_stage_ops(uint32_t n_ops, unsigned long long **keys, uint32_t **op_new, float **op_d) { return hx_group_stage(this, n_ops, grp, keys, op_new, op_d); }
-    int links_run_grouped(uint32_t n_ops, const unsigned long long *keys, const uint32_t *op_new, const float *op_d, uint64_t *n_pairs, uint32_t stats[2]);
+    // on_device: the ops already sit in grp.d_keys / d_new / d_d (hx_group_reserve + the batch pipeline's emission kernel); want_xrec: every updated
+    // list is also written as a record {target, layer, cnt, ids[2m], d[2m]} into d_xl (xl_records of hx_xrec_words(m) words) for the multi-GPU exchange
+    int links_run_grouped(uint32_t n_ops, const unsigned long long *keys, const uint32_t *op_new, const float *op_d, uint64_t *n_pairs, uint32_t stats[2],
+                          bool on_device = false, bool want_xrec = false);
+    uint32_t *d_xl = nullptr; size_t cap_xl = 0; uint32_t xl_records = 0;
+    // device-resident batch pipeline (hx_batch.hip)
+    HxBatchWork bw;
+    int db_reserve_records(uint64_t n_records);
+    int db_fill_record(uint32_t *d_rec, uint32_t slot, const uint32_t *h_src);
+    int db_dup_candidates(uint32_t base, uint32_t b, const uint32_t *d_rec, std::vector<uint32_t> &za, std::vector<uint32_t> &zb,
+                          std::vector<uint32_t> &ha, std::vector<uint32_t> &hb);
+    int db_apply(uint32_t base, uint32_t b, const uint32_t *d_rec, const uint8_t *h_dup, uint32_t rank, uint32_t world, uint32_t *n_ops_out);
+    int db_import_lists(const uint32_t *d_xrec, uint32_t n_records);
     HxGroupWork grp;
     int links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
                   const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs,
                   bool want_lists = true);   // false: the updated lists stay in the mirror only (the host pulls them when it needs them)
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
-                  uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr, uint32_t roomy = 1);   // roomy > 1: retry of overflowed tasks with that many times the visited table and candidate heap
+                  uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr, uint32_t roomy = 1, const HxFusedDev *dev = nullptr);   // roomy > 1: retry of overflowed tasks with that many times the visited table and candidate heap
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 

@@ -24,6 +24,7 @@ struct LinksParams {
     uint32_t n_groups; const uint32_t *target, *layer, *op_off, *op_new; const float *op_d;
     const uint32_t *gmap;   // launch index -> group (nullptr: identity); the groups of a batch are split between k_links_cached and k_links_hub
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; unsigned long long *n_pairs;
+    uint32_t *xrec; uint32_t xrec_words;   // multi-GPU builds: the updated list of group g as a self-describing record {target, layer, cnt, ids[2m], d[2m]} at xrec + g * xrec_words
     uint32_t dbg;   // timing experiments only (HX_LK_DBG): 1 skip pair math, 2 skip row loads, 4 skip select
 };
 
@@ -174,7 +175,12 @@ k_links(const LinksParams p)
         gl_ids[threadIdx.x] = lid[threadIdx.x]; gl_d[threadIdx.x] = ld[threadIdx.x];
         if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + threadIdx.x] = lid[threadIdx.x]; p.out_d[(size_t)g * 2u * p.m + threadIdx.x] = ld[threadIdx.x]; }
     }
-    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, pairs); }
+    if (p.xrec) {
+        uint32_t *xr = p.xrec + (size_t)g * p.xrec_words;
+        if (threadIdx.x < cnt) { xr[3 + threadIdx.x] = lid[threadIdx.x]; xr[3 + 2u * p.m + threadIdx.x] = __builtin_bit_cast(unsigned int, ld[threadIdx.x]); }
+        if (threadIdx.x == 0) { xr[0] = target; xr[1] = layer; xr[2] = cnt; }
+    }
+    if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; if (p.out_cnt) p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, pairs); }
 }
 
 // =================================================================================================
@@ -382,6 +388,11 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
         for (uint32_t i = lane; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64) dst[i] = M[i];
         if (lane == 0) pm_valid[target] = (uint8_t)v;
     }
+    if (p.xrec) {
+        uint32_t *xr = p.xrec + (size_t)g * p.xrec_words;
+        if (lane < cnt) { xr[3 + lane] = lid[lane]; xr[3 + 2u * p.m + lane] = __builtin_bit_cast(unsigned int, ld[lane]); }
+        if (lane == 0) { xr[0] = target; xr[1] = layer; xr[2] = cnt; }
+    }
     if (lane == 0) { *gl_cnt = (uint16_t)cnt; if (p.out_cnt) p.out_cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
     if (tm && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk[5] = __builtin_amdgcn_s_memtime() - tk0; for (int i = 0; i < 6; i++) atomicAdd(p.n_pairs + 1 + i, tk[i]); }
 }
@@ -469,6 +480,11 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
         float *dst = pm + (size_t)target * LC_TRI;
         for (uint32_t i = threadIdx.x; i < (v > 1 ? v * (v - 1) / 2 : 0u); i += 64 * HUB_W) dst[i] = M[i];
         if (threadIdx.x == 0) pm_valid[target] = (uint8_t)v;
+    }
+    if (p.xrec) {
+        uint32_t *xr = p.xrec + (size_t)g * p.xrec_words;
+        if (threadIdx.x < cnt) { xr[3 + threadIdx.x] = lid[threadIdx.x]; xr[3 + 2u * p.m + threadIdx.x] = __builtin_bit_cast(unsigned int, ld[threadIdx.x]); }
+        if (threadIdx.x == 0) { xr[0] = target; xr[1] = layer; xr[2] = cnt; }
     }
     if (threadIdx.x == 0) { *gl_cnt = (uint16_t)cnt; if (p.out_cnt) p.out_cnt[g] = cnt; }
     if (lane == 0) atomicAdd(p.n_pairs, ndist);
@@ -599,7 +615,7 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     p.op_off = (const uint32_t *)(mr.d_lk + o_off); p.op_new = (const uint32_t *)(mr.d_lk + o_new); p.op_d = (const float *)(mr.d_lk + o_od);
     p.out_ids = (uint32_t *)(mr.d_lk + o_ids); p.out_d = (float *)(mr.d_lk + o_d); p.out_cnt = (uint32_t *)(mr.d_lk + o_cnt);
     p.n_pairs = (unsigned long long *)(mr.d_lk + o_ctr);
-    p.gmap = nullptr;
+    p.gmap = nullptr; p.xrec = nullptr; p.xrec_words = 0;
     { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
@@ -641,15 +657,18 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     return HX_OK;
 }
 
-int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys, const uint32_t *op_new, const float *op_d, uint64_t *n_pairs, uint32_t stats[2])
+int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys, const uint32_t *op_new, const float *op_d, uint64_t *n_pairs, uint32_t stats[2],
+                                 bool on_device, bool want_xrec)
 {
     HxMirror &mr = mirror;
     stats[0] = stats[1] = 0;
     if (n_pairs) *n_pairs = 0;
+    xl_records = 0;
     if (n_ops == 0) return HX_OK;
-    if (2 * mr.m != LC_SLOTS || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "device-side op grouping serves m = 16 and rows <= 8 KiB");
+    if (2 * mr.m > LC_SLOTS || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "device-side op grouping serves m <= 16 and rows <= 8 KiB");
     HX_HIP(this, hipSetDevice(device));
-    if (mr.cap_pm < mr.cap) {                                   // pair-matrix cache for every layer-0 list (as in links_run)
+    const bool use_pm = 2 * mr.m == LC_SLOTS;                     // the resident pair-matrix cache is laid out for 32-slot lists
+    if (use_pm && mr.cap_pm < mr.cap) {                           // pair-matrix cache for every layer-0 list (as in links_run)
         float *npm = nullptr; uint8_t *nv = nullptr;
         HX_HIP(this, hipMalloc((void **)&npm, (size_t)mr.cap * LC_TRI * sizeof(float)));
         HX_HIP(this, hipMalloc((void **)&nv, mr.cap));
@@ -673,7 +692,7 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
     }
     static const uint32_t hub_min = getenv("HX_HUB_MIN") ? (uint32_t)atoi(getenv("HX_HUB_MIN")) : 48u;
     uint32_t c[4];
-    int rc = hx_group_ops(this, n_ops, keys, op_new, op_d, hub_min, grp, c);
+    int rc = on_device ? hx_group_run(this, n_ops, hub_min, grp, c) : hx_group_ops(this, n_ops, keys, op_new, op_d, hub_min, grp, c);
     if (rc) return rc;
     const uint32_t n_groups = c[0], n_hub = c[1], n_norm = c[2];
     stats[0] = n_groups; stats[1] = c[3];
@@ -682,11 +701,26 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
     p.l0_ids = mr.d_l0_ids; p.l0_d = mr.d_l0_d; p.l0_cnt = mr.d_l0_cnt; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_d = mr.d_up_d; p.up_cnt = mr.d_up_cnt;
     p.n_groups = n_groups; p.target = grp.tg; p.layer = grp.ly; p.op_off = grp.off; p.op_new = grp.op_new; p.op_d = grp.op_d; p.gmap = nullptr;
     p.out_ids = nullptr; p.out_d = nullptr; p.out_cnt = nullptr;
+    p.xrec = nullptr; p.xrec_words = 0;
+    if (want_xrec) {
+        const uint32_t xw = hx_xrec_words(mr.m);
+        const size_t need = (size_t)n_groups * xw * 4;
+        if (need > cap_xl) {
+            HX_HIP(this, hipStreamSynchronize(stream));
+            if (d_xl) (void)hipFree(d_xl);
+            d_xl = nullptr; cap_xl = 0;
+            HX_HIP(this, hipMalloc((void **)&d_xl, need * 2));
+            cap_xl = need * 2;
+        }
+        p.xrec = d_xl; p.xrec_words = xw; xl_records = n_groups;
+    }
     p.n_pairs = (unsigned long long *)mr.d_lk;
     { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
     HX_HIP(this, hipMemsetAsync(mr.d_lk, 0, 64, stream));
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
+    float *pm_save = mr.d_pm;
+    if (!use_pm) mr.d_pm = nullptr;                              // lists of other sizes are pruned from scratch (matrix in LDS only)
     if (n_hub) {
         LinksParams ph = p; ph.n_groups = n_hub; ph.gmap = grp.gmap_hub;
 #define F32C(K) ls = launch_links_hub<OpF32<K>>(this, ph)
@@ -694,17 +728,17 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
         HX_DISPATCH(this, F32C, F16C, ls = launch_links_hub<OpHamming>(this, ph), ls = launch_links_hub<OpJaccard>(this, ph));
 #undef F32C
 #undef F16C
-        HX_HIP(this, ls);
     }
-    if (n_norm) {
+    if (ls == hipSuccess && n_norm) {
         p.n_groups = n_norm; p.gmap = grp.gmap_norm;
 #define F32C(K) ls = launch_links_cached<OpF32<K>>(this, p)
 #define F16C(K) ls = launch_links_cached<OpF16<K>>(this, p)
         HX_DISPATCH(this, F32C, F16C, ls = launch_links_cached<OpHamming>(this, p), ls = launch_links_cached<OpJaccard>(this, p));
 #undef F32C
 #undef F16C
-        HX_HIP(this, ls);
     }
+    mr.d_pm = pm_save;
+    HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
     HX_HIP(this, hipMemcpyAsync(mr.h_lk, mr.d_lk, 64, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));

@@ -13,6 +13,12 @@ rows (288 GB of HBM per GPU makes that free) and of the graph, and each batch is
 so the graph after every batch is bit-identical on all ranks and identical to the single-GPU build with the same
 batch schedule.  The only data-path collectives are those two all_gathers per batch.  Batches smaller than
 `min_shard` members are built redundantly on every rank (a collective would cost more than it saves).
+
+Two exchange formats.  Device-resident (default whenever hx_index_dbatch_supported: m <= 16, rows <= 8 KiB, no level draw beyond
+the traversal kernel's layers): k_fused<insert> writes the members' lists into a torch-allocated DEVICE buffer, RCCL all-gathers
+that buffer, every rank scatters it into its graph copy on the device, the back-link kernels write the lists they pruned as
+device records, RCCL all-gathers those, and a kernel scatters the other ranks' records -- no list ever visits the host.  Host
+format (hx_index_batch_*: serialized host buffers) remains for the batches the device kernels do not serve.
 """
 import time
 
@@ -57,9 +63,58 @@ def gather_sizes(n, dist, device):
     return [int(x) for x in out.cpu().tolist()]
 
 
-def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_shard=256, size_fn=None):
+def all_gather_device(send, world, dist, device):
+    """All-gathers equal-sized uint8 device tensors.  `device` is where the backend wants its tensors (the GPU for nccl = RCCL over
+    xGMI; the CPU for gloo rehearsals, which stage through host memory)."""
+    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
+    if torch.device(device).type == "cuda":
+        dist.all_gather_into_tensor(recv, send)
+        torch.cuda.current_stream(send.device).synchronize()      # the engine reads the buffer on its own stream
+    else:
+        host = torch.empty(world * send.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, send.cpu())
+        recv.copy_(host)
+        torch.cuda.synchronize(send.device)
+    return recv
+
+
+def _device_batch(ix, first_row, levels, tids, dist, device, gpu, world, rank):
+    """One batch through the device-resident stages; returns the elements holding the batch's tids."""
+    b = len(levels)
+    per = -(-b // world)                                          # member i lives in record i: rank r fills records [r*per, r*per+per)
+    lo, hi = min(b, rank * per), min(b, rank * per + per)
+    rb, lb = ix.dbatch_record_bytes, ix.dbatch_list_record_bytes
+    t0 = time.perf_counter()
+    ix.dbatch_begin(first_row, levels, tids)
+    t0 = _t("begin", t0)
+    send = torch.zeros(per * rb, dtype=torch.uint8, device=gpu)
+    torch.cuda.current_stream(gpu).synchronize()                  # the engine runs on its own (non-blocking) stream
+    ix.dbatch_search(lo, hi, send.data_ptr())
+    t0 = _t("search", t0)
+    recs = all_gather_device(send, world, dist, device)
+    t0 = _t("allgather_new", t0)
+    mine = ix.dbatch_links(rank, world, recs.data_ptr())
+    t0 = _t("links", t0)
+    sizes = gather_sizes(mine, dist, device)
+    cap = max(max(sizes), 1)
+    lsend = torch.zeros(cap * lb, dtype=torch.uint8, device=gpu)
+    torch.cuda.current_stream(gpu).synchronize()
+    ix.dbatch_export_links(lsend.data_ptr())
+    t0 = _t("export_links", t0)
+    lrecv = all_gather_device(lsend, world, dist, device)
+    t0 = _t("allgather_links", t0)
+    for r in range(world):
+        if r != rank and sizes[r]:
+            ix.dbatch_import_links(lrecv.data_ptr() + r * cap * lb, sizes[r])
+    out = ix.dbatch_end(b)                                        # synchronises the engine's stream: the buffers may go
+    _t("import_links", t0)
+    return out
+
+
+def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_shard=256, size_fn=None, gpu=None):
     """hx_index_insert for rows [first_row, first_row + len(levels)) with every batch shared by the ranks.
-    `ix` exposes the staged batch API of binding.Index (tests drive this with a stand-in object and gloo)."""
+    `ix` exposes the staged batch API of binding.Index (tests drive this with a stand-in object and gloo).
+    gpu: torch device of this rank's engine; given, batches the device kernels serve exchange device buffers."""
     world, rank = dist.get_world_size(), dist.get_rank()
     levels = np.ascontiguousarray(levels, np.int32)
     n = len(levels)
@@ -75,6 +130,11 @@ def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_sh
             t0 = time.perf_counter()
             elems[done:done + b] = ix.insert(first_row + done, levels[done:done + b], tids[done:done + b], batch=b)
             _t("replicated_small_batches", t0)
+            done += b
+            continue
+        if gpu is not None and ix.dbatch_supported(levels[done:done + b]):
+            elems[done:done + b] = _device_batch(ix, first_row + done, levels[done:done + b], tids[done:done + b], dist, device, gpu, world, rank)
+            STAGE_SECONDS["device_batches"] = STAGE_SECONDS.get("device_batches", 0) + 1
             done += b
             continue
         lo, hi = slice_bounds(b, world)

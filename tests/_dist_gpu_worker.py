@@ -1,0 +1,80 @@
+"""Worker for test_dist_gpu.py: one rank of a multi-process build with the REAL engine (every rank on cuda:0, collectives over
+gloo), through pgvector-rx_amd/dist_build.insert_sharded.  Prints a digest of the rank's final graph."""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pgvector_rx_amd as hx  # noqa: E402
+
+db = importlib.import_module("pgvector-rx_amd.dist_build")
+
+
+def graph_digest(ix, n):
+    h = hashlib.sha256()
+    lv = ix.export_levels()
+    h.update(lv.tobytes())
+    h.update(np.int64(ix.entry).tobytes())
+    for layer in range(int(max(lv.max(), 0)) + 1):
+        ids, d, cnt = ix.export_layer(layer)
+        lm = ids.shape[1]
+        valid = np.arange(lm)[None, :] < cnt[:, None]
+        h.update(cnt.tobytes())
+        h.update(np.where(valid, ids, 0).tobytes())
+        h.update(np.where(valid, d.view(np.uint32), 0).tobytes())
+    for i in range(n):
+        h.update(np.asarray(ix.heaptids(i), np.int64).tobytes())
+    return h.hexdigest()
+
+
+class OneRank:
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def get_rank():
+        return 0
+
+
+def main():
+    n, dim, m, efc, batch, dt, metric, fmt = (int(x) for x in sys.argv[1:9])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    rng = np.random.default_rng(123)
+    if dt == hx.F32:
+        rows = rng.random((n, dim)).astype(np.float32)
+    elif dt == hx.F16:
+        rows = rng.random((n, dim)).astype(np.float16).view(np.uint16)
+    else:
+        rows = np.packbits(rng.integers(0, 2, (n, dim)).astype(np.uint8), axis=1, bitorder="big")
+    rows[n // 2] = rows[7]                 # a duplicate of an old row, and a pair of identical rows inside one batch
+    rows[n // 2 + 5] = rows[n // 2 + 3]
+    levels = hx.draw_levels(n, m, seed=5)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+    else:
+        d = OneRank
+    gpu = torch.device("cuda", 0)
+    e = hx.Engine(dt, metric, dim, n, device=0)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    elems = db.insert_sharded(ix, 0, levels, batch, d, torch.device("cpu"), min_shard=16, gpu=gpu if fmt else None)
+    stages = dict(db.STAGE_SECONDS)
+    print("DIGEST %s size=%d elems=%s device_batches=%d fused_redone=%d" % (
+        graph_digest(ix, n), ix.size, hashlib.sha256(elems.tobytes()).hexdigest()[:16], int(stages.get("device_batches", 0)), ix.fused_stats()["redone"]), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ix.close()
+    e.close()
+
+
+if __name__ == "__main__":
+    main()

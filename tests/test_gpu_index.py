@@ -235,6 +235,31 @@ def test_duplicates_20_identical_rows_on_device():
     e.close()
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "lockstep"])
+@pytest.mark.parametrize("batch", [64, 500])
+def test_duplicates_inside_one_batch(fused, batch):
+    """Identical rows arriving in ONE batch cannot meet through the graph; they are merged all the same (device row hashes + byte
+    comparison), in the order the sequential schedule would merge them: 20 identical rows -> 2 elements of 10 heap TIDs
+    (tests/t/015_hnsw_vector_duplicates.pl:24-37), also when an older element with room exists (it is filled first)."""
+    rng = np.random.default_rng(15)
+    n, dim, m, efc = 700, 6, 8, 32
+    rows = make_rows(hx.F32, n, dim, rng)
+    rows[300:320] = rows[300]            # 20 identical rows, one batch
+    rows[400:404] = rows[20]             # copies of an old row: merged through the graph
+    rows[410] = rows[405]                # a pair inside the batch
+    rows[650:662] = rows[300]            # 12 more copies of the 20, a later batch: the second element is full after 0, so a third appears
+    levels = hx.draw_levels(n, m, seed=15)
+    e, ix, elem, o, oelem = build_both(hx.F32, hx.L2SQ, dim, rows, levels, m, efc, batch, fused)
+    assert elem.tolist() == oelem.tolist()
+    assert_same_graph(ix, o, n)
+    live = sorted(set(int(x) for x in elem[300:320]))
+    assert len(live) == 2 and sorted(len(ix.heaptids(i)) for i in live) == [10, 10]
+    assert all(int(x) == 20 for x in elem[400:404]) and elem[410] == 405
+    assert len(set(int(x) for x in elem[650:662])) == 2
+    ix.close()
+    e.close()
+
+
 def test_option_limits():
     e = hx.Engine(hx.F32, hx.L2SQ, 3, 8)
     for m, efc in [(1, 64), (101, 1000), (16, 3), (16, 1001), (16, 31)]:      # options.rs:203-225, build.rs:865-867
@@ -372,6 +397,61 @@ def test_staged_batches_two_rank_simulation(fused):
     for _, ix in ranks:
         got = ix.search(16, 40, 10)
         assert (got[0] == ref[0]).all() and (got[1].view(np.uint32) == ref[1].view(np.uint32)).all()
+    for e, ix in ranks + [(e0, ix0)]:
+        ix.close()
+        e.close()
+
+
+def test_device_batches_two_rank_simulation():
+    """The device-resident exchange of pgvector-rx_amd/dist_build.py played by two engines on one GPU: member records and
+    pruned-list records move between the 'ranks' as device buffers only; both replicas must equal the oracle's graph."""
+    import torch
+    rng = np.random.default_rng(78)
+    n, dim, m, efc, batch, world = 2500, 24, 16, 64, 256, 2
+    rows = make_rows(hx.F32, n, dim, rng)
+    rows[300] = rows[5]
+    rows[1203] = rows[1200]
+    levels = hx.draw_levels(n, m, seed=3)
+    tids = np.arange(n, dtype=np.int64)
+    e0, ix0, _, o, _ = build_both(hx.F32, hx.L2SQ, dim, rows, levels, m, efc, batch)
+    ranks = []
+    for r in range(world):
+        e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+        e.append(rows)
+        ranks.append((e, hx.Index(e, m, efc)))
+    rb, lb = ranks[0][1].dbatch_record_bytes, ranks[0][1].dbatch_list_record_bytes
+    done, n_dev = 0, 0
+    for b in hx.batch_schedule(0, n, batch):
+        lv, td = levels[done:done + b], tids[done:done + b]
+        if ranks[0][1].entry < 0 or b < 16 or not ranks[0][1].dbatch_supported(lv):
+            for _, ix in ranks:
+                ix.insert(done, lv, td, batch=b)
+            done += b
+            continue
+        n_dev += 1
+        per = -(-b // world)
+        recs = torch.zeros(world * per * rb, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()                                                 # the engines run on their own streams
+        for r, (_, ix) in enumerate(ranks):
+            ix.dbatch_begin(done, lv, td)
+            lo, hi = min(b, r * per), min(b, r * per + per)
+            ix.dbatch_search(lo, hi, recs.data_ptr() + lo * rb)                 # "all-gather": both ranks write into the one buffer
+        counts = [ix.dbatch_links(r, world, recs.data_ptr()) for r, (_, ix) in enumerate(ranks)]
+        bufs = []
+        for r, (_, ix) in enumerate(ranks):
+            t = torch.zeros(max(counts[r], 1) * lb, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ix.dbatch_export_links(t.data_ptr())
+            bufs.append(t)
+        for r, (_, ix) in enumerate(ranks):
+            for s in range(world):
+                if s != r and counts[s]:
+                    ix.dbatch_import_links(bufs[s].data_ptr(), counts[s])
+            ix.dbatch_end(b)
+        done += b
+    assert n_dev >= 5
+    for _, ix in ranks:
+        assert_same_graph(ix, o, n)
     for e, ix in ranks + [(e0, ix0)]:
         ix.close()
         e.close()
