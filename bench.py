@@ -43,9 +43,10 @@ def parse():
     p.add_argument("--batch", type=int, default=8192, help="lock-step insert batch cap")
     p.add_argument("--dist", default="gmm", choices=["gmm", "uniform"])
     p.add_argument("--threads", type=int, default=0)
-    p.add_argument("--cpu-build-rows", type=int, default=1500)
+    p.add_argument("--cpu-build-rows", type=int, default=600)
     p.add_argument("--cpu-queries", type=int, default=300)
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-k1-1536", action="store_true", help="skip the K1 micro-benchmark on a vector(1536) table")
     p.add_argument("--no-fused", action="store_true", help="run every traversal in the lock-step host driver")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo = rehearsal of the multi-rank build with CPU-side exchange (several ranks may share one GPU)")
@@ -91,37 +92,102 @@ def recall_at_k(tids, cnt, gt, k):
     return hit / (gt.shape[0] * k)
 
 
+class Comm:
+    """The process group the build's collectives run on (dist_build.py only needs these four calls)."""
+
+    def __init__(self, dist, group, backend):
+        self.dist, self.group, self.backend = dist, group, backend
+
+    def get_world_size(self):
+        return self.dist.get_world_size(self.group)
+
+    def get_rank(self):
+        return self.dist.get_rank(self.group)
+
+    def all_gather_into_tensor(self, out, inp):
+        return self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_reduce(self, t, op=None):
+        return self.dist.all_reduce(t, op=op or self.dist.ReduceOp.SUM, group=self.group)
+
+    def barrier(self):
+        return self.dist.barrier(group=self.group)
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (fresh children, before this process makes any
+    GPU call -- a process that touched the GPU must never be re-executed) and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if not a.share_gpu and visible < a.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (a.gpus, visible), file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(max(abs(rc) for rc in rcs))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world != a.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr, flush=True)
+        raise SystemExit(2)
     import torch.distributed as dist
     if a.share_gpu:
         local_rank = 0
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.dist_backend == "nccl":
-            try:   # RCCL over xGMI; a rendezvous / first-collective failure falls back to gloo (host tensors) so the run still measures
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-                probe = torch.ones(1, device=torch.device("cuda", local_rank))
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as ex:   # noqa: BLE001
-                print("bench.py: nccl backend unavailable (%s); using gloo" % (str(ex).splitlines()[0] if str(ex) else type(ex).__name__), file=sys.stderr, flush=True)
-                try:
-                    dist.destroy_process_group()
-                except Exception:   # noqa: BLE001
-                    pass
-                a.dist_backend = "gloo"
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1 and torch.cuda.device_count() < world:
+        print("bench.py: %d ranks but only %d GPU(s) visible" % (world, torch.cuda.device_count()), file=sys.stderr, flush=True)
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    xdev = dev if a.dist_backend == "nccl" else torch.device("cpu")     # where collectives' tensors live
+    comm = None
+    if world > 1:
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # gloo first: rendezvous, timing reductions, and the place where the ranks AGREE on the data-path backend (a rank that
+        # failed to bring RCCL up must not leave its peers waiting inside an RCCL collective)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        comm = Comm(dist, dist.group.WORLD, "gloo")
+        if a.dist_backend == "nccl":
+            ok, grp, why = 1, None, ""
+            try:   # RCCL over xGMI
+                try:
+                    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
+                except TypeError:
+                    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=grp)
+                torch.cuda.synchronize()
+                ok = int(probe.item() == world)
+            except Exception as ex:   # noqa: BLE001
+                ok, why = 0, (str(ex).splitlines()[0] if str(ex) else type(ex).__name__)
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm = Comm(dist, grp, "nccl")
+            else:
+                if not ok:
+                    print("bench.py: rank %d could not bring up the nccl (RCCL) backend (%s); every rank uses gloo" % (rank, why), file=sys.stderr, flush=True)
+                a.dist_backend = "gloo"
+    xdev = dev if (comm is not None and comm.backend == "nccl") else torch.device("cpu")     # where the data-path collectives' tensors live
 
     def barrier():
         if world > 1:
@@ -151,14 +217,14 @@ def main():
     if world > 1:
         from importlib import import_module
         dbm = import_module("pgvector-rx_amd.dist_build")
-        dbm.insert_sharded(ix, 0, levels, eff_batch, dist, xdev)
+        dbm.insert_sharded(ix, 0, levels, eff_batch, comm, xdev, gpu=dev)
         dist_stages = {k: round(v, 3) for k, v in dbm.STAGE_SECONDS.items()}
     else:
         ix.insert(0, levels, batch=eff_batch)
     barrier()
     build_sec = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([build_sec], device=xdev, dtype=torch.float64)
+        t = torch.tensor([build_sec], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         build_sec = float(t.item())
     build_stats = {"dist": eng.kernel_stats(0, reset=True), "pair": eng.kernel_stats(1, reset=True), "fused": eng.kernel_stats(2, reset=True), "links": eng.kernel_stats(3, reset=True)}
@@ -178,7 +244,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=xdev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     sstat = eng.kernel_stats(0)
@@ -205,10 +271,34 @@ def main():
               "frac": round(k1_gbps / HBM_PEAK_GBPS, 4), "launches": ks["launches"], "avg_launch_ms": round(ks["ms"] / ks["launches"], 4),
               "distances_per_launch": g_n * per, "bytes_per_distance": a.dim * 4}
 
+        # the same kernel at the north-star shape of its >= 50 % target: vector(1536) (a table of its own, 256k rows = 1.6 GB)
+        if not a.no_k1_1536:
+            d2, n2 = 1536, 262144
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(7)
+            t2 = torch.rand((n2, d2), generator=g2, device=dev, dtype=torch.float32)
+            torch.cuda.synchronize()
+            e2 = hx.Engine(hx.F32, hx.L2SQ, d2, n2, device=local_rank)
+            e2.append_device(t2.data_ptr(), n2)
+            e2.set_timing(True)
+            gq2 = rng.integers(0, n2, g_n).astype(np.uint32)
+            gids2 = rng.integers(0, n2, g_n * per).astype(np.uint32)
+            e2.distances_batch(gq2, goff, gids2)
+            e2.kernel_stats(0, reset=True)
+            for _ in range(10):
+                e2.distances_batch(gq2, goff, gids2)
+            ks2 = e2.kernel_stats(0, reset=True)
+            gb2 = ks2["units"] * d2 * 4 / max(ks2["ms"], 1e-9) / 1e6
+            k1["d1536"] = {"kernel": "k_dist_groups", "bound": "hbm", "achieved": round(gb2, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gb2 / HBM_PEAK_GBPS, 4),
+                           "launches": ks2["launches"], "avg_launch_ms": round(ks2["ms"] / ks2["launches"], 4), "distances_per_launch": g_n * per,
+                           "bytes_per_distance": d2 * 4, "table_rows": n2}
+            e2.close()
+            del t2
+
     gt = ground_truth(rows, queries, a.k)
     recall = recall_at_k(tids, cnt, gt, a.k)
     if world > 1:
-        t = torch.tensor([recall], device=xdev, dtype=torch.float64)
+        t = torch.tensor([recall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         recall = float(t.item()) / world
 
@@ -273,18 +363,11 @@ def main():
     cpu = None
     if not a.no_cpu and world == 1:
         from oracle import orc
-        n_cb = min(a.cpu_build_rows, a.rows)
-        host_rows = rows[:n_cb].cpu().numpy()
-        o = orc.Index(orc.F32, orc.L2SQ, a.dim, m=a.m, ef_construction=a.efc, order=orc.SEQ)
-        t0 = time.perf_counter()
-        o.build(host_rows, levels[:n_cb], batch=1)
-        cpu_build = time.perf_counter() - t0
-        del o
-        # search baseline: the scalar scan on the SAME 1M graph the device built
+        # search baseline: the scalar scan on the SAME graph the device built
         all_rows = rows.cpu().numpy()
         o = orc.Index(orc.F32, orc.L2SQ, a.dim, m=a.m, ef_construction=a.efc, order=orc.SEQ)
         lv = ix.export_levels()
-        layers = [ix.export_layer(l, with_dist=False) for l in range(int(max(lv.max(), 0)) + 1)]
+        layers = [ix.export_layer(l, with_dist=True) for l in range(int(max(lv.max(), 0)) + 1)]
         o.load(all_rows, lv, ix.entry, layers)
         hq = queries[:a.cpu_queries].cpu().numpy()
         t0 = time.perf_counter()
@@ -308,6 +391,16 @@ def main():
         ids_all, cnt_all = o.search_many(hq_all, a.efs, a.k, n_threads=host_threads)
         cpu_all = time.perf_counter() - t0
         hits_all = sum(len(set(ids_all[q, :cnt_all[q]].tolist()) & set(gt[q].tolist())) for q in range(nq_all))
+        # build baseline: the reference's sequential build_callback (one row at a time, one core) inserting fresh rows of the same
+        # distribution INTO the full-size graph the device built -- the per-row cost at this index size, not that of a tiny graph
+        n_cb = a.cpu_build_rows
+        extra, _ = synth(n_cb, a.dim, a.dist, 13, dev, centres)
+        extra = extra.cpu().numpy()
+        extra_levels = hx.draw_levels(n_cb, a.m, seed=13)
+        t0 = time.perf_counter()
+        for i in range(n_cb):
+            o.insert(extra[i], extra_levels[i], a.rows + i)
+        cpu_build = time.perf_counter() - t0
         del o
         ov = orc.Index(orc.F32, orc.L2SQ, a.dim, m=a.m, ef_construction=a.efc, order=orc.VEC)
         ov.load(all_rows, lv, ix.entry, layers)
@@ -327,7 +420,7 @@ def main():
                          "omits fmgr/bufmgr/lock overhead so it is faster than the reference itself" % (len(hq), a.efs, a.rows),
                "recall_at_10": round(hits / (len(hq) * a.k), 4),
                "build_rows_per_s": round(n_cb / cpu_build, 2),
-               "build_sample": "sequential oracle build of the first %d rows from an empty index: %.1f s" % (n_cb, cpu_build),
+               "build_sample": "sequential oracle inserts (build_callback, one core) of %d fresh rows into the %d-row graph the device built: %.1f s" % (n_cb, a.rows, cpu_build),
                "host_cpus": os.cpu_count(), **cpu_more}
 
     out = {
@@ -349,6 +442,7 @@ def main():
         "build_kernels": build_kernels,
         "host_profile": {"build": {k: round(v, 2) for k, v in build_prof.items()}, "search_all_steps": {k: round(v, 3) for k, v in search_prof.items()}},
         "fused": ix.fused_stats(),
+        "dist_backend": (comm.backend if comm is not None else None),
         "dist_build_stage_seconds_rank0": dist_stages,
         "build_distance_evals": {"search": int(counters[1]), "select": int(counters[2]), "backlink": int(counters[3])},
     }
