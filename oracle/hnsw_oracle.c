@@ -128,8 +128,8 @@ static float acc_seq(int kind, int dtype, int dim, const void *a, const void *b)
     return acc;
 }
 
-/* device canonical order (see header) */
-static float acc_w64(int kind, int dtype, int dim, const void *a, const void *b)
+/* device canonical order (see header): the plain restatement ... */
+static float acc_w64_plain(int kind, int dtype, int dim, const void *a, const void *b)
 {
     const int V = (dtype == ORC_F32) ? 4 : 8;
     float p[64], t[64];
@@ -146,6 +146,56 @@ static float acc_w64(int kind, int dtype, int dim, const void *a, const void *b)
     }
     return p[0];
 }
+/* ... and the same sums arranged so that the compiler can run the 64 lane accumulators side by side (the GPU tests build graphs of
+ * thousands of wide rows through this order): per 64*V-element chunk the terms are formed first, then added to the lane partials for
+ * k = 0..V-1 in turn -- each partial still receives its own terms in ascending (chunk, k) order, mul and add rounded separately.
+ * tests/test_oracle_golden.py checks it against acc_w64_plain bit for bit. */
+static const float *h2f_table(void)
+{   /* half_to_f32 (halfvec.rs:54-87) of all 65 536 halves, computed once */
+    static float *tab = NULL; static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&mu);
+    if (!tab) { float *t = malloc(65536 * sizeof(float)); for (int i = 0; i < 65536; i++) t[i] = orc_half_to_f32((uint16_t)i); tab = t; }
+    pthread_mutex_unlock(&mu);
+    return tab;
+}
+#define W64_BODY(V, LOADA, LOADB)                                                                                   \
+    float p[64] = {0}, t[64 * V], u[64];                                                                            \
+    const int CH = 64 * V;                                                                                          \
+    int c0 = 0;                                                                                                     \
+    for (; c0 + CH <= dim; c0 += CH) {                                                                              \
+        if (kind == T_L2) for (int i = 0; i < CH; i++) { const float d = LOADA(c0 + i) - LOADB(c0 + i); t[i] = d * d; } \
+        else if (kind == T_IP) for (int i = 0; i < CH; i++) t[i] = LOADA(c0 + i) * LOADB(c0 + i);                   \
+        else for (int i = 0; i < CH; i++) t[i] = fabsf(LOADA(c0 + i) - LOADB(c0 + i));                              \
+        for (int k = 0; k < V; k++) for (int l = 0; l < 64; l++) p[l] = p[l] + t[l * V + k];                        \
+    }                                                                                                               \
+    for (int i = c0; i < dim; i++) { const int l = (i - c0) / V; p[l] = p[l] + term(kind, LOADA(i), LOADB(i)); }     \
+    for (int off = 32; off >= 1; off >>= 1) { for (int l = 0; l < 64; l++) u[l] = p[l] + p[l ^ off]; memcpy(p, u, sizeof p); } \
+    return p[0];
+__attribute__((optimize("O3", "fp-contract=off"), target_clones("avx512f", "avx2", "default")))
+static float acc_w64_f32(int kind, int dim, const float *a, const float *b)
+{
+#define LA(i) a[i]
+#define LB(i) b[i]
+    W64_BODY(4, LA, LB)
+#undef LA
+#undef LB
+}
+__attribute__((optimize("O3", "fp-contract=off"), target_clones("avx512f", "avx2", "default")))
+static float acc_w64_f16(int kind, int dim, const uint16_t *a, const uint16_t *b, const float *tab)
+{
+#define LA(i) tab[a[i]]
+#define LB(i) tab[b[i]]
+    W64_BODY(8, LA, LB)
+#undef LA
+#undef LB
+}
+static float acc_w64(int kind, int dtype, int dim, const void *a, const void *b)
+{
+    if (dtype == ORC_F32) return acc_w64_f32(kind, dim, (const float *)a, (const float *)b);
+    return acc_w64_f16(kind, dim, (const uint16_t *)a, (const uint16_t *)b, h2f_table());
+}
+ORC_API float orc_acc_w64_plain(int kind, int dtype, int dim, const void *a, const void *b) { return acc_w64_plain(kind, dtype, dim, a, b); }
+ORC_API float orc_acc_w64_fast(int kind, int dtype, int dim, const void *a, const void *b) { return acc_w64(kind, dtype, dim, a, b); }
 
 /* ORC_ORDER_VEC: a reassociated, compiler-vectorised CPU variant (16 partial sums, AVX-512 / AVX2 picked at load time).
  * It is NOT the reference's arithmetic (the reference is the scalar loop above); it exists only so that bench.py can

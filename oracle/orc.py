@@ -76,6 +76,8 @@ def lib():
             "orc_bruteforce_topk": (i32, [vp, vp, i32, vp, vp]),
             "orc_distances_many": (None, [i32, i32, i32, vp, vp, vp, i32, i32, vp]),
             "orc_pairwise": (None, [i32, i32, i32, vp, vp, i32, i32, vp]),
+            "orc_acc_w64_plain": (f32, [i32, i32, i32, vp, vp]),
+            "orc_acc_w64_fast": (f32, [i32, i32, i32, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -305,42 +305,6 @@ def test_c1_recall_config():
     e.close()
 
 
-@pytest.mark.parametrize("gate", G["recall_gates"][:1], ids=lambda g: g["ref"].split("/")[-1])
-def test_reference_recall_gate_on_device(gate):
-    """tests/t/012_hnsw_vector_build_recall.pl:94 at its full size (10 000 x vector(3), k=20)."""
-    rng = np.random.default_rng(12)
-    n, dim, k = gate["rows"], gate["dim"], gate["k"]
-    raw = (rng.random((n, dim)) * rng.random((n, dim))).astype(np.float32)
-    qs = rng.random((gate["queries"], dim)).astype(np.float32)
-    levels = hx.draw_levels(n, gate["m"], seed=12)
-    for metric, min_recall in gate["min_recall"].items():
-        cosine = metric == "cosine"
-        e = hx.Engine(hx.F32, METRIC[metric], dim, n)
-        e.append(raw)
-        if cosine:
-            assert (e.normalize_rows(0, n) > 0).all()
-        ix = hx.Index(e, gate["m"], gate["ef_construction"])
-        ix.insert(0, levels, batch=128)
-        e.set_queries(qs, normalize=cosine)
-        tids, _, _, cnt = ix.search(len(qs), gate["ef_search"], k)
-        r64, q64 = raw.astype(np.float64), qs.astype(np.float64)
-        correct = 0
-        for q in range(len(qs)):
-            if metric == "l2":
-                dist = ((r64 - q64[q]) ** 2).sum(1)
-            elif metric == "ip":
-                dist = -(r64 @ q64[q])
-            elif metric == "l1":
-                dist = np.abs(r64 - q64[q]).sum(1)
-            else:
-                dist = 1.0 - (r64 @ q64[q]) / np.sqrt((r64 ** 2).sum(1) * (q64[q] ** 2).sum())
-            exact = set(np.argsort(dist, kind="stable")[:k].tolist())
-            correct += len(exact & set(tids[q, :cnt[q]].tolist()))
-        assert correct / (k * len(qs)) >= min_recall, (metric, correct / (k * len(qs)))
-        ix.close()
-        e.close()
-
-
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "lockstep"])
 def test_staged_batches_two_rank_simulation(fused):
     """The multi-GPU protocol of pgvector-rx_amd/dist_build.py, played by two engines on one GPU: each 'rank' searches

@@ -312,3 +312,61 @@ def test_search_many_threads_equal_single_and_vec_order_within_tolerance():
             v = orc.distance(orc.F32, metric, d, a, b, order=orc.VEC)
             scale = float(np.abs(a.astype(np.float64) * b).sum()) if metric == orc.NEG_IP else abs(s)
             assert abs(s - v) <= 1e-5 * max(scale, 1e-30)
+
+
+def test_w64_fast_order_equals_plain_restatement():
+    """The lane-parallel arrangement of ORC_ORDER_W64 (what graph builds run through) gives the bits of its plain restatement."""
+    L = orc.lib()
+    rng = np.random.default_rng(64)
+    for dt in (orc.F32, orc.F16):
+        for dim in list(range(1, 20)) + [63, 64, 65, 255, 256, 257, 511, 512, 513, 768, 1536, 2000] + ([4000] if dt == orc.F16 else []):
+            for kind in (0, 1, 2):
+                if dt == orc.F32:
+                    a = (rng.standard_normal(dim) * 10.0 ** rng.uniform(-3, 3)).astype(np.float32)
+                    b = rng.standard_normal(dim).astype(np.float32)
+                else:
+                    a = rng.integers(0, 0x7C00, dim).astype(np.uint16)
+                    b = (rng.integers(0, 0x7C00, dim) | (rng.integers(0, 2, dim) << 15)).astype(np.uint16)
+                x = np.float32(L.orc_acc_w64_plain(kind, dt, dim, a.ctypes.data, b.ctypes.data))
+                y = np.float32(L.orc_acc_w64_fast(kind, dt, dim, a.ctypes.data, b.ctypes.data))
+                assert x.view(np.uint32) == y.view(np.uint32), (dt, dim, kind)
+
+
+def _iter_gate_expected(rows64, q64, metric, c, limit):
+    if metric == "l2":
+        d = np.sqrt(((rows64 - q64) ** 2).sum(1))
+    else:
+        d = 1.0 - (rows64 @ q64) / np.sqrt((rows64 ** 2).sum(1) * (q64 ** 2).sum())
+    ids = np.arange(1, len(d) + 1)
+    top = np.sort(d[ids % c == 0])[:limit]
+    return set(ids[d <= top[-1]].tolist())
+
+
+@pytest.mark.parametrize("gate", G["iterative_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
+def test_iterative_recall_gate(gate):
+    """tests/t/044_hnsw_iterative_scan_recall.pl: `WHERE i % c = 0 ORDER BY v <-> q LIMIT 20` under strict_order / relaxed_order
+    must find >= 0.99 of the exact answer (the oracle runs the gate at a reduced row count to keep the CPU suite short)."""
+    rng = np.random.default_rng(44)
+    n, dim, limit = 12000, gate["dim"], gate["limit"]
+    raw = rng.random((n, dim)).astype(np.float32)
+    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    levels = orc.levels_from_seed(n, gate["m"], 44)
+    for metric in gate["metrics"]:
+        idx = orc.Index(orc.F32, METRIC[metric], dim, m=gate["m"], ef_construction=gate["ef_construction"])
+        for i in range(n):
+            r = raw[i]
+            if metric == "cosine":
+                r, norm = orc.l2_normalize(orc.F32, dim, r)
+                assert norm > 0
+            idx.insert(r, levels[i], i + 1)                      # i = 1..n as in generate_series(1, n)
+        for c in (50, 120):                                      # 500 of 50 000 rows -> the same 1-in-100ish selectivity at this size
+            for mode in gate["modes"]:
+                it = orc.ITER_STRICT if mode == "strict_order" else orc.ITER_RELAXED
+                correct = total = 0
+                for q in qs:
+                    qq = orc.l2_normalize(orc.F32, dim, q)[0] if metric == "cosine" else q
+                    got = [t for t, _, _ in idx.scan(qq, ef_search=gate["ef_search"], iterative=it, max_scan_tuples=20000) if t % c == 0][:limit]
+                    ok = _iter_gate_expected(raw.astype(np.float64), q.astype(np.float64), metric, c, limit)
+                    correct += sum(1 for t in got if t in ok)
+                    total += limit
+                assert correct / total >= gate["min_recall"], (metric, c, mode, correct / total)
