@@ -222,6 +222,34 @@ int hx_engine::db_reserve_records(uint64_t n_records)
     return HX_OK;
 }
 
+// W tables of the batch's members: 2^k >= 2 * ef_construction entries each (off above 512: the table is built in the traversal kernel's LDS)
+int hx_engine::db_begin_wtabs(uint32_t base, uint32_t b, uint32_t ef_construction)
+{
+    static const bool off = getenv("HX_WTAB") && atoi(getenv("HX_WTAB")) == 0;
+    bw.wt_size = 0; bw.wt_base = base; bw.wt_n = b;
+    if (off || ef_construction > 512 || b == 0) return HX_OK;
+    uint32_t T = 64; while (T < 2 * ef_construction) T <<= 1;
+    HX_HIP(this, hipSetDevice(device));
+    const size_t need = (size_t)b * T * 8;
+    if (need > bw.cap_wtab) {
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (bw.d_wtab) (void)hipFree(bw.d_wtab);
+        bw.d_wtab = nullptr; bw.cap_wtab = 0;
+        HX_HIP(this, hipMalloc(&bw.d_wtab, need + need / 2));
+        bw.cap_wtab = need + need / 2;
+    }
+    if (b > bw.cap_wtv) {
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (bw.d_wt_valid) (void)hipFree(bw.d_wt_valid);
+        bw.d_wt_valid = nullptr; bw.cap_wtv = 0;
+        HX_HIP(this, hipMalloc((void **)&bw.d_wt_valid, (size_t)b * 2));
+        bw.cap_wtv = (size_t)b * 2;
+    }
+    HX_HIP(this, hipMemsetAsync(bw.d_wt_valid, 0, b, stream));
+    bw.wt_size = T;
+    return HX_OK;
+}
+
 int hx_engine::db_fill_record(uint32_t *d_rec, uint32_t slot, const uint32_t *h_src)
 {
     const uint32_t m = mirror.m, words = HX_FUSED_MAXL + 2u * HX_FUSED_MAXL * 2u * m;

@@ -34,6 +34,8 @@ struct FusedParams {
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; uint32_t *status;
     uint32_t o_cst, o_lst;                        // MODE 1 output strides in 32-bit words: out_cnt[s*o_cst + layer], out_ids/out_d[s*o_lst + layer*2m + k] (status[t] stays per task)
     const uint32_t *t_oslot;                      // MODE 1: output slot s of task t (nullptr: s = t)
+    uint2 *wtab; uint32_t wt_size, wt_slot0; uint8_t *wt_valid;   // MODE 1: the layer-0 result set W of task t as an open-addressing table of wt_size {d, id} entries at
+                                                  // wtab + (wt_slot0 + s) * wt_size (the back-link kernels look d(new row, x) up there instead of streaming row x); nullptr: off
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
     // iterative scan (k_fused MODE 2): hnsw.iterative_scan relaxed_order (1) / strict_order (2), scan.rs:794-875
     uint32_t iter_mode, limit; long long max_tuples;
@@ -235,6 +237,18 @@ __device__ __forceinline__ bool vis_test_and_set(uint32_t *tab, uint32_t bmask, 
     if (vis_lookup(tab, bmask, key, slot)) return true;
     vis_settle(tab, bmask, key, slot, atomicCAS(slot, VIS_EMPTY, key));
     return false;
+}
+
+// W table of an insert (written by k_fused<insert>, read by the back-link kernels): d(new row, key) if the new row's layer-0 search evaluated it
+__device__ __forceinline__ bool wt_lookup(const uint2 *tab, uint32_t mask, uint32_t key, float &d)
+{
+    uint32_t s = vis_mix(key) & mask;
+    for (;;) {
+        const uint2 e = tab[s];
+        if (e.y == key) { d = __builtin_bit_cast(float, e.x); return true; }
+        if (e.y == VIS_EMPTY) return false;
+        s = (s + 1u) & mask;
+    }
 }
 
 struct FusedCtx {

@@ -395,6 +395,24 @@ k_fused(const FusedParams p_in)
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
                 n_ep = wl;
+                if (lc == 0 && p.wtab) {
+                    // W (ids + distance bits) as a hash table for the back-link kernels: built in the candidate heap's LDS (dead until the
+                    // next search), copied out coalesced.  d(new, x) there is the very value a back-link prune would recompute.
+                    lds_uint2 *T = cx.CH.lds; const uint32_t tm = p.wt_size - 1u;
+                    for (uint32_t i = lane; i < p.wt_size; i += 64) { T[i].x = 0u; T[i].y = VIS_EMPTY; }
+                    __syncthreads();
+                    for (uint32_t i = lane; i < wl; i += 64) {
+                        const uint2 e = cx.EP[i];
+                        uint32_t s = vis_mix(e.y) & tm;
+                        while (atomicCAS((uint32_t *)&T[s].y, VIS_EMPTY, e.y) != VIS_EMPTY) s = (s + 1u) & tm;
+                        T[s].x = e.x;
+                    }
+                    __syncthreads();
+                    uint2 *dst = p.wtab + (size_t)(p.wt_slot0 + os) * p.wt_size;
+                    for (uint32_t i = lane; i < p.wt_size; i += 64) dst[i] = make_uint2(T[i].x, T[i].y);
+                    if (lane == 0 && p.wt_valid) p.wt_valid[p.wt_slot0 + os] = 1;
+                    __syncthreads();
+                }
                 // select_neighbors(W, lm): mod.rs:269-308
                 const unsigned long long ts0 = (p.fdbg & 4u) ? __builtin_amdgcn_s_memtime() : 0ull;
                 uint32_t r = 0, nd = 0;

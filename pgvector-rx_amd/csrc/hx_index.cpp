@@ -1251,6 +1251,7 @@ int hx_index_dbatch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const in
     // from here on the mirror is the only place this batch's lists exist
     int rc = ix->sync_mirror();
     if (rc) { ix->rollback_batch(); return rc; }
+    if ((rc = ix->e->db_begin_wtabs(bs.base, b, (uint32_t)ix->efc))) { ix->rollback_batch(); return ix->fail(rc, ix->e->err); }
     return HX_OK;
 }
 
@@ -1268,6 +1269,7 @@ int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_recor
     for (uint32_t i = 0; i < n; i++) { qsel[i] = bs.base + lo + i; tl[i] = g.level[bs.base + lo + i]; }
     uint64_t cnts[2] = {0, 0};
     HxFusedDev dev; dev.d_rec = (uint32_t *)d_records; dev.rec_words = rw;
+    if (ix->e->bw.wt_size) { dev.d_wtab = ix->e->bw.d_wtab; dev.wt_size = ix->e->bw.wt_size; dev.wt_slot0 = lo; dev.d_wt_valid = ix->e->bw.d_wt_valid; }
     int rc;
     const double t0 = hx_index::now_s();
     if ((rc = ix->e->fused_run(1, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,

@@ -58,7 +58,8 @@ struct HxFusedView { const uint32_t *ids = nullptr, *cnt = nullptr, *status = nu
 
 // insert-mode results written straight into device records (a batch's exchange buffer, hx_batch.hip): record r =
 // cnt[HX_FUSED_MAXL] | ids[HX_FUSED_MAXL][2m] | d[HX_FUSED_MAXL][2m], rec_words 32-bit words apart; task t fills record h_slots[t] (nullptr: t)
-struct HxFusedDev { uint32_t *d_rec = nullptr; uint32_t rec_words = 0; const uint32_t *h_slots = nullptr; };
+struct HxFusedDev { uint32_t *d_rec = nullptr; uint32_t rec_words = 0; const uint32_t *h_slots = nullptr;
+                    void *d_wtab = nullptr; uint32_t wt_size = 0, wt_slot0 = 0; uint8_t *d_wt_valid = nullptr; };   // W tables of the members (hx_fused_core.h FusedParams::wtab)
 
 // device-side grouping of a batch's back-link ops (hx_group.hip): workspace + the grouped arrays it leaves on the device
 struct HxGroupWork {
@@ -71,6 +72,8 @@ struct HxBatchWork {
     uint8_t *d = nullptr; size_t cap = 0;               // device scratch (hashes, candidate pairs, op counts)
     uint8_t *h = nullptr; size_t cap_h = 0; uint32_t *h_ctr = nullptr;   // pinned staging and counters
     uint32_t *d_rec = nullptr; size_t cap_rec = 0;      // member records of single-process batches (multi-GPU builds pass their exchange buffer instead)
+    void *d_wtab = nullptr; size_t cap_wtab = 0; uint8_t *d_wt_valid = nullptr; size_t cap_wtv = 0;   // the members' W tables (d(new, x) of their layer-0 searches) for the back-link kernels
+    uint32_t wt_size = 0, wt_base = 0, wt_n = 0;        // entries per table (0: off); element ids [wt_base, wt_base + wt_n) are the open batch's members
 };
 uint32_t hx_rec_words(uint32_t m);                      // 32-bit words per member record: cnt[HX_FUSED_MAXL] | ids[HX_FUSED_MAXL][2m] | d[HX_FUSED_MAXL][2m]
 struct hx_engine;
@@ -126,6 +129,7 @@ struct hx_engine {
     // device-resident batch pipeline (hx_batch.hip)
     HxBatchWork bw;
     int db_reserve_records(uint64_t n_records);
+    int db_begin_wtabs(uint32_t base, uint32_t b, uint32_t ef_construction);   // sizes and clears the W tables of a new batch
     int db_fill_record(uint32_t *d_rec, uint32_t slot, const uint32_t *h_src);
     int db_dup_candidates(uint32_t base, uint32_t b, const uint32_t *d_rec, std::vector<uint32_t> &za, std::vector<uint32_t> &zb,
                           std::vector<uint32_t> &ha, std::vector<uint32_t> &hb);

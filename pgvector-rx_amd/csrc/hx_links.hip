@@ -24,9 +24,89 @@ struct LinksParams {
     uint32_t n_groups; const uint32_t *target, *layer, *op_off, *op_new; const float *op_d;
     const uint32_t *gmap;   // launch index -> group (nullptr: identity); the groups of a batch are split between k_links_cached and k_links_hub
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; unsigned long long *n_pairs;
+    const uint2 *wtab; uint32_t wt_size, wt_base, wt_n; const uint8_t *wt_valid;   // W tables of the open batch's members (FusedParams::wtab); nullptr: off
     uint32_t *xrec; uint32_t xrec_words;   // multi-GPU builds: the updated list of group g as a self-describing record {target, layer, cnt, ids[2m], d[2m]} at xrec + g * xrec_words
     uint32_t dbg;   // timing experiments only (HX_LK_DBG): 1 skip pair math, 2 skip row loads, 4 skip select
 };
+
+// Pair matrix (packed lower triangle, LDS) of the n <= 33 rows sid[0..n): every thread of the 512-thread workgroup calls this.
+template <class OP>
+__device__ __forceinline__ void lk_pair_matrix(const LinksParams &p, uint8_t *bufs, const uint32_t buf_bytes, const uint32_t *sid, const uint32_t n,
+                                               float *tri, const uint32_t lane, const uint32_t wave)
+{
+    // ---- pair matrix of the n candidate rows.  Rows 1..n-1 of the triangle are paired (r, n-r) -- r + (n-r) = n <= 33
+    // pairs per row-pair -- and wave w owns row-pairs q = w and q = 15 - w (r = q + 1).  For a row-pair, accumulator
+    // A[j] is pair (n-r, j), j < n-r, and A[32-j] is pair (r, j), j < r (disjoint because n <= 33).  A wave reads
+    // its 4 "a" fragments once per chunk and each b_j fragment once for up to 4 pairs: 36 LDS reads per chunk
+    // instead of 132, and 4 independent accumulation chains per read. ----
+    uint32_t rr[2], hh[2]; bool use_r[2], use_h[2];
+#pragma unroll
+    for (int q2 = 0; q2 < 2; q2++) {
+        const uint32_t q = q2 == 0 ? wave : 15u - wave;
+        const uint32_t r = q + 1, h = n - r;                   // r <= 16
+        use_h[q2] = r < n && h > r;                            // partner row strictly above r
+        use_r[q2] = r < n && h >= r;                           // r itself (also the lone middle row when h == r)
+        rr[q2] = r; hh[q2] = use_h[q2] ? h : 0u;
+    }
+    uint32_t rid[LK_STAGE];
+#pragma unroll
+    for (int t = 0; t < LK_STAGE; t++) { const uint32_t r = wave + t * HX_PAIR_WAVES; rid[t] = r < n ? sid[r] : 0u; }
+    typename OP::acc_t acc[HX_PAIRS_PER_WAVE];                 // [0..32] row-pair 0, [33..65] row-pair 1
+#pragma unroll
+    for (int s2 = 0; s2 < HX_PAIRS_PER_WAVE; s2++) OP::init(acc[s2]);
+    u4 pre[LK_STAGE];
+    auto prefetch = [&](uint32_t c0) {
+        const uint32_t off = c0 + lane * 16u;
+#pragma unroll
+        for (int t = 0; t < LK_STAGE; t++) {
+            u4 v = {0u, 0u, 0u, 0u};
+            if (wave + t * HX_PAIR_WAVES < n && off < p.pitch && !(p.dbg & 2u)) v = *(const u4 *)(p.rows + (size_t)rid[t] * p.pitch + off);
+            pre[t] = v;
+        }
+    };
+    prefetch(0);
+    uint32_t bufsel = 0;
+    for (uint32_t c0 = 0; c0 < p.pitch; c0 += 1024u, bufsel ^= 1u) {
+        uint8_t *buf = bufs + bufsel * buf_bytes;
+#pragma unroll
+        for (int t = 0; t < LK_STAGE; t++) {
+            const uint32_t r = wave + t * HX_PAIR_WAVES;
+            if (r < n) *(u4 *)(buf + r * 1024u + lane * 16u) = pre[t];
+        }
+        __syncthreads();
+        if (c0 + 1024u < p.pitch) prefetch(c0 + 1024u);
+        if (p.dbg & 1u) continue;
+        const u4 ar0 = *(const u4 *)(buf + rr[0] * 1024u + lane * 16u), ah0 = *(const u4 *)(buf + hh[0] * 1024u + lane * 16u);
+        const u4 ar1 = *(const u4 *)(buf + rr[1] * 1024u + lane * 16u), ah1 = *(const u4 *)(buf + hh[1] * 1024u + lane * 16u);
+        const uint32_t jmax = n - 1u;                          // largest row index any wave needs as "b" is n-2
+#pragma unroll
+        for (int j = 0; j < LK_MAXN - 1; j++) {
+            if ((uint32_t)j < jmax) {
+                const u4 bj = *(const u4 *)(buf + (uint32_t)j * 1024u + lane * 16u);
+                if (use_h[0] && (uint32_t)j < hh[0]) OP::add(acc[j], ah0, bj);
+                if (use_r[0] && (uint32_t)j < rr[0]) OP::add(acc[32 - j], ar0, bj);
+                if (use_h[1] && (uint32_t)j < hh[1]) OP::add(acc[33 + j], ah1, bj);
+                if (use_r[1] && (uint32_t)j < rr[1]) OP::add(acc[33 + 32 - j], ar1, bj);
+            }
+        }
+    }
+    {
+        float res0 = 0.f, res1 = 0.f;
+        if (!(p.dbg & 32u)) reduce_pairs<OP, HX_PAIRS_PER_WAVE>(acc, lane, res0, res1);
+        // lane l holds accumulator l (< 64); lanes 0,1 also hold accumulators 64, 65
+#pragma unroll
+        for (int part = 0; part < 2; part++) {
+            const uint32_t sidx = part == 0 ? lane : 64u + lane;
+            const float val = part == 0 ? res0 : res1;
+            if (part == 1 && lane >= HX_PAIRS_PER_WAVE - 64) continue;
+            const uint32_t q2 = sidx >= 33u ? 1u : 0u, k = sidx - 33u * q2;
+            const uint32_t r = q2 ? rr[1] : rr[0], h = q2 ? hh[1] : hh[0];
+            const bool uh = q2 ? use_h[1] : use_h[0], ur = q2 ? use_r[1] : use_r[0];
+            if (uh && k < h) tri[h * (h - 1) / 2 + k] = val;
+            else if (ur && 32u - k < r) tri[r * (r - 1) / 2 + (32u - k)] = val;
+        }
+    }
+}
 
 template <class OP>
 __global__ void __launch_bounds__(HX_PAIR_WG, LK_MINW)
@@ -76,79 +156,8 @@ k_links(const LinksParams p)
             sid[rank] = lid[threadIdx.x]; sd[rank] = d;
         }
         __syncthreads();
-        // ---- pair matrix of the n candidate rows.  Rows 1..n-1 of the triangle are paired (r, n-r) -- r + (n-r) = n <= 33
-        // pairs per row-pair -- and wave w owns row-pairs q = w and q = 15 - w (r = q + 1).  For a row-pair, accumulator
-        // A[j] is pair (n-r, j), j < n-r, and A[32-j] is pair (r, j), j < r (disjoint because n <= 33).  A wave reads
-        // its 4 "a" fragments once per chunk and each b_j fragment once for up to 4 pairs: 36 LDS reads per chunk
-        // instead of 132, and 4 independent accumulation chains per read. ----
+        lk_pair_matrix<OP>(p, bufs, buf_bytes, sid, n, tri, lane, wave);
         const uint32_t P = n * (n - 1) / 2;
-        uint32_t rr[2], hh[2]; bool use_r[2], use_h[2];
-#pragma unroll
-        for (int q2 = 0; q2 < 2; q2++) {
-            const uint32_t q = q2 == 0 ? wave : 15u - wave;
-            const uint32_t r = q + 1, h = n - r;                   // r <= 16
-            use_h[q2] = r < n && h > r;                            // partner row strictly above r
-            use_r[q2] = r < n && h >= r;                           // r itself (also the lone middle row when h == r)
-            rr[q2] = r; hh[q2] = use_h[q2] ? h : 0u;
-        }
-        uint32_t rid[LK_STAGE];
-#pragma unroll
-        for (int t = 0; t < LK_STAGE; t++) { const uint32_t r = wave + t * HX_PAIR_WAVES; rid[t] = r < n ? sid[r] : 0u; }
-        typename OP::acc_t acc[HX_PAIRS_PER_WAVE];                 // [0..32] row-pair 0, [33..65] row-pair 1
-#pragma unroll
-        for (int s2 = 0; s2 < HX_PAIRS_PER_WAVE; s2++) OP::init(acc[s2]);
-        u4 pre[LK_STAGE];
-        auto prefetch = [&](uint32_t c0) {
-            const uint32_t off = c0 + lane * 16u;
-#pragma unroll
-            for (int t = 0; t < LK_STAGE; t++) {
-                u4 v = {0u, 0u, 0u, 0u};
-                if (wave + t * HX_PAIR_WAVES < n && off < p.pitch && !(p.dbg & 2u)) v = *(const u4 *)(p.rows + (size_t)rid[t] * p.pitch + off);
-                pre[t] = v;
-            }
-        };
-        prefetch(0);
-        uint32_t bufsel = 0;
-        for (uint32_t c0 = 0; c0 < p.pitch; c0 += 1024u, bufsel ^= 1u) {
-            uint8_t *buf = bufs + bufsel * buf_bytes;
-#pragma unroll
-            for (int t = 0; t < LK_STAGE; t++) {
-                const uint32_t r = wave + t * HX_PAIR_WAVES;
-                if (r < n) *(u4 *)(buf + r * 1024u + lane * 16u) = pre[t];
-            }
-            __syncthreads();
-            if (c0 + 1024u < p.pitch) prefetch(c0 + 1024u);
-            if (p.dbg & 1u) continue;
-            const u4 ar0 = *(const u4 *)(buf + rr[0] * 1024u + lane * 16u), ah0 = *(const u4 *)(buf + hh[0] * 1024u + lane * 16u);
-            const u4 ar1 = *(const u4 *)(buf + rr[1] * 1024u + lane * 16u), ah1 = *(const u4 *)(buf + hh[1] * 1024u + lane * 16u);
-            const uint32_t jmax = n - 1u;                          // largest row index any wave needs as "b" is n-2
-#pragma unroll
-            for (int j = 0; j < LK_MAXN - 1; j++) {
-                if ((uint32_t)j < jmax) {
-                    const u4 bj = *(const u4 *)(buf + (uint32_t)j * 1024u + lane * 16u);
-                    if (use_h[0] && (uint32_t)j < hh[0]) OP::add(acc[j], ah0, bj);
-                    if (use_r[0] && (uint32_t)j < rr[0]) OP::add(acc[32 - j], ar0, bj);
-                    if (use_h[1] && (uint32_t)j < hh[1]) OP::add(acc[33 + j], ah1, bj);
-                    if (use_r[1] && (uint32_t)j < rr[1]) OP::add(acc[33 + 32 - j], ar1, bj);
-                }
-            }
-        }
-        {
-            float res0 = 0.f, res1 = 0.f;
-            if (!(p.dbg & 32u)) reduce_pairs<OP, HX_PAIRS_PER_WAVE>(acc, lane, res0, res1);
-            // lane l holds accumulator l (< 64); lanes 0,1 also hold accumulators 64, 65
-#pragma unroll
-            for (int part = 0; part < 2; part++) {
-                const uint32_t sidx = part == 0 ? lane : 64u + lane;
-                const float val = part == 0 ? res0 : res1;
-                if (part == 1 && lane >= HX_PAIRS_PER_WAVE - 64) continue;
-                const uint32_t q2 = sidx >= 33u ? 1u : 0u, k = sidx - 33u * q2;
-                const uint32_t r = q2 ? rr[1] : rr[0], h = q2 ? hh[1] : hh[0];
-                const bool uh = q2 ? use_h[1] : use_h[0], ur = q2 ? use_r[1] : use_r[0];
-                if (uh && k < h) tri[h * (h - 1) / 2 + k] = val;
-                else if (ur && 32u - k < r) tri[r * (r - 1) / 2 + (32u - k)] = val;
-            }
-        }
         pairs += P;
         __syncthreads();
         // ---- select_neighbors(candidates, lm) on the matrix: mod.rs:284-305 ----
@@ -199,6 +208,38 @@ k_links(const LinksParams p)
 #define LC_TRI (LC_SLOTS * (LC_SLOTS - 1) / 2)     /* 496 */
 __device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > j ? i * (i - 1) / 2 + j : j * (j - 1) / 2 + i; }
 
+// =================================================================================================
+// k_pm_fill: the resident pair matrix of a FULL layer-0 list that is about to see its first prune (or whose cache the host
+//   invalidated), computed the K2 way -- the 32 rows staged through LDS once, 496 pairs from LDS -- instead of by k_links_cached's
+//   in-wave fill, which streams slot s against slots < s (496 row reads for the same 32 rows: measured as 60 % of the back-link
+//   kernels' row traffic on the 1M x 768 build).  One 512-thread workgroup per group of the batch; groups that need nothing return at once.
+// =================================================================================================
+template <class OP>
+__global__ void __launch_bounds__(HX_PAIR_WG, LK_MINW)
+k_pm_fill(const LinksParams p, float *pm, uint8_t *pm_valid)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t buf_bytes = LK_MAXN * 1024u;
+    uint8_t *bufs = lds;
+    uint32_t *lid = (uint32_t *)(lds + 2 * buf_bytes);           // list ids [40]
+    float *tri = (float *)(lid + 40);                            // packed lower triangle [528]
+    const uint32_t g = blockIdx.x;
+    if (g >= p.n_groups || p.layer[g] != 0u) return;
+    const uint32_t target = p.target[g], lm = 2u * p.m;
+    const uint32_t cnt = p.l0_cnt[target];
+    if (cnt != lm || pm_valid[target] >= cnt) return;            // not full yet (appends come first), or already cached
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < cnt) lid[threadIdx.x] = p.l0_ids[(size_t)target * lm + threadIdx.x];
+    __syncthreads();
+    lk_pair_matrix<OP>(p, bufs, buf_bytes, lid, cnt, tri, lane, wave);
+    __syncthreads();
+    float *dst = pm + (size_t)target * LC_TRI;
+    for (uint32_t i = threadIdx.x; i < cnt * (cnt - 1u) / 2u; i += HX_PAIR_WG) dst[i] = tri[i];
+    if (threadIdx.x == 0) { pm_valid[target] = (uint8_t)cnt; atomicAdd(p.n_pairs, (unsigned long long)(cnt * (cnt - 1u) / 2u)); }
+}
+
+
 // One back-link op (new_id at distance new_d) on the list held in LDS: update_neighbor_connections' body, mod.rs:458-487.
 // Runs in ONE wave (wave-level ordering only), on the list state (M, lid, ld, cnt, v) and the scratch arrays it is given.
 // SPEC == false: applies the op; returns true when the list was pruned (it is then in select order, its matrix complete).
@@ -207,7 +248,8 @@ __device__ __forceinline__ uint32_t lc_tri(uint32_t i, uint32_t j) { return i > 
 template <class OP, int LPR, bool SPEC>
 __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
                       float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, uint8_t *QV,
-                      uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist, unsigned long long *tk = nullptr)
+                      uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist, unsigned long long *tk = nullptr,
+                      const uint2 *wt = nullptr, const uint32_t wt_mask = 0)
 {
     unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
 #define LC_TICK(k) do { if (tk) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[k] += t_ - tq; tq = t_; } } while (0)
@@ -249,20 +291,36 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
         }
         F_WSYNC();
         LC_TICK(1);                                                                // sort
+        // d(new row, slot) the new row's own layer-0 search already evaluated: one probe of its W table per slot (a 1-hop gather of 8 bytes
+        // instead of streaming a row); only the slots it never met are streamed below.  Same bits either way.
+        unsigned long long known = 0ull;
+        if (wt) {
+            bool f = false;
+            if (lane < cnt) { float dv = 0.0f; f = wt_lookup(wt, wt_mask, lid[lane], dv); if (f) nd[lane] = dv; }
+            known = __ballot(f);
+            F_WSYNC();
+        }
+        const unsigned long long cmask = (1ull << cnt) - 1ull;                      // cnt <= 32
+        const uint32_t n_unk = (uint32_t)__popcll(~known & cmask);
         // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
         uint32_t r = 0, ndc = 0, n_done = 0;      // n_done: how many entries of the evaluation order ORD have their nd[]
         bool ordered = false; unsigned long long amask = 0ull;   // slots accepted so far
         uint32_t my_slot = 0;                      // lane j: slot of the j-th accepted candidate
-        auto finish_nd = [&]() {                  // all remaining d(new, slot)
-            if (!ordered) {
-                if (lane < cnt) { IDS[lane] = lid[lane]; ORD[lane] = lane; }
-                f_park_w(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
-                ordered = true;
+        auto order_unknown = [&](const unsigned long long first) {   // evaluation order of the slots still to be streamed: those in `first` first
+            const unsigned long long u = ~known & cmask, a = u & first, rest = u & ~first, below = (1ull << lane) - 1ull;
+            if (lane < cnt && ((u >> lane) & 1ull)) {
+                const uint32_t o = ((a >> lane) & 1ull) ? (uint32_t)__popcll(a & below) : (uint32_t)__popcll(a) + (uint32_t)__popcll(rest & below);
+                IDS[o] = lid[lane]; ORD[o] = lane;
             }
-            if (n_done < cnt) {
-                const float d = f_dist_batch<OP, LPR, LC_RB>(fp, QV, IDS + n_done, cnt - n_done, lane);
-                if (lane < cnt - n_done) nd[ORD[n_done + lane]] = d;
-                ndist += cnt - n_done; n_done = cnt;
+            if (n_unk) f_park_w(fp, p.rows + (size_t)new_id * p.pitch, lane, QV); else F_WSYNC();
+            ordered = true;
+        };
+        auto finish_nd = [&]() {                  // all remaining d(new, slot)
+            if (!ordered) order_unknown(0ull);
+            if (n_done < n_unk) {
+                const float d = f_dist_batch<OP, LPR, LC_RB>(fp, QV, IDS + n_done, n_unk - n_done, lane);
+                if (lane < n_unk - n_done) nd[ORD[n_done + lane]] = d;
+                ndist += n_unk - n_done; n_done = n_unk;
             }
             F_WSYNC();
         };
@@ -272,24 +330,21 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
             bool closer;
             if (si == LC_SLOTS) {
                 LC_TICK(2);                                                        // walk so far
-                // accepted slots first in the evaluation order
-                const bool acc = lane < cnt && ((amask >> lane) & 1ull) != 0ull;
-                const unsigned long long am = amask, below = (1ull << lane) - 1ull;
-                const uint32_t na = (uint32_t)__popcll(am);
-                if (lane < cnt) {
-                    const uint32_t o = acc ? (uint32_t)__popcll(am & below) : na + (uint32_t)__popcll(~am & below);
-                    IDS[o] = lid[lane]; ORD[o] = lane;
-                }
-                f_park_w(fp, p.rows + (size_t)new_id * p.pitch, lane, QV);
-                ordered = true;
-                bool hit = false;
-                constexpr uint32_t B = f_step_rows<LPR>();
-                for (uint32_t j0 = 0; j0 < na && !hit; j0 += B) {
-                    const uint32_t nb = na - j0 < B ? na - j0 : B;
-                    const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + j0, nb, lane);
-                    if (lane < nb) nd[ORD[j0 + lane]] = d;
-                    ndist += nb; n_done = j0 + nb;
-                    hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
+                // accepted slots decide (mod.rs:324-336): first the ones whose distance is already known, then the rest streamed
+                // FUSED_RB at a time, stopping at the first batch with a hit like check_element_closer's early return
+                const unsigned long long am = amask;
+                bool hit = __ballot(lane < cnt && ((am >> lane) & 1ull) && ((known >> lane) & 1ull) && nd[lane] <= ed) != 0ull;
+                if (!hit) {
+                    order_unknown(am);
+                    const uint32_t na = (uint32_t)__popcll(am & ~known & cmask);
+                    constexpr uint32_t B = f_step_rows<LPR>();
+                    for (uint32_t j0 = 0; j0 < na && !hit; j0 += B) {
+                        const uint32_t nb = na - j0 < B ? na - j0 : B;
+                        const float d = f_dist_batch<OP, LPR>(fp, QV, IDS + j0, nb, lane);
+                        if (lane < nb) nd[ORD[j0 + lane]] = d;
+                        ndist += nb; n_done = j0 + nb;
+                        hit = __ballot(lane < nb && d <= ed) != 0ull;                  // mod.rs:333-335
+                    }
                 }
                 closer = !hit;
                 LC_TICK(3);                                                        // lazy distances of the new row
@@ -341,6 +396,15 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
 #undef LC_TICK
 }
 
+// the W table of the element a back-link op adds, if it is a member of the open batch whose layer-0 search ran on this GPU
+__device__ __forceinline__ const uint2 *lk_wtab(const LinksParams &p, uint32_t layer, uint32_t new_id)
+{
+    if (!p.wtab || layer != 0u) return nullptr;
+    const uint32_t k = new_id - p.wt_base;
+    if (k >= p.wt_n || (p.wt_valid && !p.wt_valid[k])) return nullptr;
+    return p.wtab + (size_t)k * p.wt_size;
+}
+
 template <class OP, int LPR>
 __global__ void __launch_bounds__(64, 4)
 k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
@@ -378,7 +442,8 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
     const bool tm = (p.dbg & 8u) != 0; const unsigned long long tk0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++)
-        (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr);
+        (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr,
+                                    lk_wtab(p, layer, p.op_new[op]), p.wt_size - 1u);
     if (lane < cnt) {
         gl_ids[lane] = lid[lane]; gl_d[lane] = ld[lane];
         if (p.out_ids) { p.out_ids[(size_t)g * 2u * p.m + lane] = lid[lane]; p.out_d[(size_t)g * 2u * p.m + lane] = ld[lane]; }
@@ -449,7 +514,8 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
         if (!canon || cnt < lm || v < cnt) {                       // appends, the first prune, missing pairs: the ordinary path, one op
             __syncthreads();
             if (wave == 0) {
-                const bool pruned = lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist);
+                const bool pruned = lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, nullptr,
+                                                          lk_wtab(p, layer, p.op_new[op]), p.wt_size - 1u);
                 if (lane == 0) { ctl[0] = op + 1u; ctl[1] = cnt; ctl[2] = v; if (pruned) ctl[3] = 1u; }
             }
             continue;
@@ -458,7 +524,8 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
         bool changed = false;
         if (wave < nv) {
             uint32_t c2 = cnt, v2 = v;
-            changed = lc_op<OP, LPR, true>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, c2, v2, lm, p.op_new[op + wave], p.op_d[op + wave], lane, ndist);
+            changed = lc_op<OP, LPR, true>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, c2, v2, lm, p.op_new[op + wave], p.op_d[op + wave], lane, ndist, nullptr,
+                                           lk_wtab(p, layer, p.op_new[op + wave]), p.wt_size - 1u);
         }
         if (lane == 0) ctl[4 + wave] = changed ? 1u : 0u;
         __syncthreads();
@@ -467,7 +534,8 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
         __syncthreads();
         if (first == nv) { if (threadIdx.x == 0) ctl[0] = op + nv; continue; }
         if (wave == 0) {
-            (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op + first], p.op_d[op + first], lane, ndist);
+            (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op + first], p.op_d[op + first], lane, ndist, nullptr,
+                                        lk_wtab(p, layer, p.op_new[op + first]), p.wt_size - 1u);
             if (lane == 0) { ctl[0] = op + first + 1u; ctl[1] = cnt; ctl[2] = v; }
         }
     }
@@ -525,6 +593,20 @@ static hipError_t launch_links_cached(hx_engine *e, const LinksParams &p)
     if (e->pitch <= 128) return launch_links_cached_lpr<OP, 8>(e, p);
     if (e->pitch <= 512) return launch_links_cached_lpr<OP, 32>(e, p);
     return launch_links_cached_lpr<OP, 64>(e, p);
+}
+
+template <class OP>
+static hipError_t launch_pm_fill(hx_engine *e, const LinksParams &p)
+{
+    const size_t lds = 2 * (size_t)LK_MAXN * 1024u + (40 + HX_PAIR_SLAB) * 4;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t s = hipFuncSetAttribute((const void *)k_pm_fill<OP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (s != hipSuccess) return s;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_pm_fill<OP>), dim3(p.n_groups), dim3(HX_PAIR_WG), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    return hipGetLastError();
 }
 
 template <class OP>
@@ -615,7 +697,7 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     p.op_off = (const uint32_t *)(mr.d_lk + o_off); p.op_new = (const uint32_t *)(mr.d_lk + o_new); p.op_d = (const float *)(mr.d_lk + o_od);
     p.out_ids = (uint32_t *)(mr.d_lk + o_ids); p.out_d = (float *)(mr.d_lk + o_d); p.out_cnt = (uint32_t *)(mr.d_lk + o_cnt);
     p.n_pairs = (unsigned long long *)(mr.d_lk + o_ctr);
-    p.gmap = nullptr; p.xrec = nullptr; p.xrec_words = 0;
+    p.gmap = nullptr; p.xrec = nullptr; p.xrec_words = 0; p.wtab = nullptr; p.wt_size = 0; p.wt_base = 0; p.wt_n = 0; p.wt_valid = nullptr;
     { const char *dv = getenv("HX_LK_DBG"); p.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
@@ -702,6 +784,8 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
     p.n_groups = n_groups; p.target = grp.tg; p.layer = grp.ly; p.op_off = grp.off; p.op_new = grp.op_new; p.op_d = grp.op_d; p.gmap = nullptr;
     p.out_ids = nullptr; p.out_d = nullptr; p.out_cnt = nullptr;
     p.xrec = nullptr; p.xrec_words = 0;
+    p.wtab = nullptr; p.wt_size = 0; p.wt_base = 0; p.wt_n = 0; p.wt_valid = nullptr;
+    if (on_device && bw.wt_size) { p.wtab = (const uint2 *)bw.d_wtab; p.wt_size = bw.wt_size; p.wt_base = bw.wt_base; p.wt_n = bw.wt_n; p.wt_valid = bw.d_wt_valid; }
     if (want_xrec) {
         const uint32_t xw = hx_xrec_words(mr.m);
         const size_t need = (size_t)n_groups * xw * 4;
@@ -720,6 +804,15 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
     float *pm_save = mr.d_pm;
+    static const bool prefill = !(getenv("HX_PM_PREFILL") && atoi(getenv("HX_PM_PREFILL")) == 0);
+    if (use_pm && prefill) {                                     // pair matrices of the full lists that are pruned for the first time
+#define F32C(K) ls = launch_pm_fill<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_pm_fill<OpF16<K>>(this, p)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_pm_fill<OpHamming>(this, p), ls = launch_pm_fill<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+        HX_HIP(this, ls);
+    }
     if (!use_pm) mr.d_pm = nullptr;                              // lists of other sizes are pruned from scratch (matrix in LDS only)
     if (n_hub) {
         LinksParams ph = p; ph.n_groups = n_hub; ph.gmap = grp.gmap_hub;
