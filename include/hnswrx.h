@@ -206,6 +206,22 @@ int hx_index_dbatch_export_links(hx_index *ix, void *d_out);
 int hx_index_dbatch_import_links(hx_index *ix, const void *d_list_records, uint64_t n);
 int hx_index_dbatch_end(hx_index *ix, uint32_t *elem_out);
 
+/* ---- f3: the on-disk paths on the engine ---------------------------------------------------------
+ * aminsert (src/index/insert.rs:1227-1480) for n rows that were already appended to the engine: find_element_neighbors_on_disk
+ * (:1021-1123 -- search_layer_disk per layer, the lm NEAREST taken without the heuristic, :1111-1117), find_duplicate_on_disk
+ * (:1180-1214), the new element's tuple, update_neighbors_on_disk / get_update_index (:883-958, :500-739 -- incl. its skipped
+ * new-vs-existing check :680-693) and the entry-point update.  batch == 1: one insert at a time, exactly the reference's result;
+ * batch > 1: the neighbour searches of `batch` rows run in lock-step against the same graph, as concurrent backends would.
+ * Serves m <= 32. */
+int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids,
+                           uint32_t batch, uint32_t *elem_out);
+/* ambulkdelete + amvacuumcleanup (src/index/vacuum.rs): dead_tids = the heap TIDs the bulk-delete callback reports dead.  Pass 1
+ * removes them (:118-217); pass 2 repairs the entry point and every element with a deleted neighbour or a layer-0 list that is
+ * not full (:230-285, :411-644) with repair_graph_element's search (:288-407: the deleted set and the element itself skipped,
+ * ef_construction + 1); pass 3 marks the emptied elements deleted (:655-793).  batch as above. */
+int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uint32_t batch, uint64_t *n_deleted_out, uint64_t *n_repaired_out);
+int hx_index_deleted(const hx_index *ix, uint32_t elem);      /* 1 after vacuum marked the element deleted */
+
 /* graph export (what create_graph_pages/write_neighbor_tuples serialise, build.rs:545-821) */
 uint32_t hx_index_size(const hx_index *ix);
 int64_t hx_index_entry(const hx_index *ix);                   /* -1 = empty */

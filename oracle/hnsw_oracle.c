@@ -406,6 +406,7 @@ typedef struct {
     cand_t **nbr;      /* [level+1][lm] */
     int64_t tids[HNSW_HEAPTIDS]; int ntids;
     int merged;        /* batch schedule only: row tombstoned as a duplicate of another element */
+    int deleted;       /* HnswElementTupleData.deleted (types/hnsw.rs:112-137): set by vacuum's mark_deleted, tested by the on-disk paths */
 } elem_t;
 
 typedef struct orc_index {
@@ -416,6 +417,7 @@ typedef struct orc_index {
     int *vis; int vis_epoch, vis_cap;/* visited "set" */
     uint64_t cnt[8];                 /* distance evaluations: [0] entry, [1] search loop, [2] select in find, [3] back-link prune, [4] scan */
     double ind_tuples;
+    int ondisk_tombstones;            /* orc_index_insert_on_disk keeps a tombstone for a merged row (the reference adds nothing) */
 } orc_index;
 
 static inline int layer_m(int m, int layer) { return layer == 0 ? 2 * m : m; }   /* hnsw_constants.rs:122-128 */
@@ -822,8 +824,8 @@ static inline double dist_scan(orc_scan *s, int e)
 
 /* search_layer_disk scan.rs:302-448.  visited: caller bitmap or NULL (=> local); discarded may be NULL.
  * Entry points carry their distances.  Output nearest-last in *out (malloc'd), returns count. */
-static int search_layer_scan(orc_scan *s, const hitem *ep, int nep, int ef, int layer,
-                             uint8_t *visited, heap_t *discarded, int add_entry_to_visited, hitem **out)
+static int search_layer_scan_skip(orc_scan *s, const hitem *ep, int nep, int ef, int layer,
+                                  uint8_t *visited, heap_t *discarded, int add_entry_to_visited, const uint8_t *skip, hitem **out)
 {
     orc_index *x = s->x;
     uint8_t *local = NULL;
@@ -832,7 +834,8 @@ static int search_layer_scan(orc_scan *s, const hitem *ep, int nep, int ef, int 
     int w_len = 0;
     for (int i = 0; i < nep; i++) {
         if (add_entry_to_visited) visited[ep[i].idx] = 1;
-        heap_push(&C, ep[i]); heap_push(&W, ep[i]); w_len++;
+        heap_push(&C, ep[i]); heap_push(&W, ep[i]);
+        if (!skip || !skip[ep[i].idx]) w_len++;                 /* skip_count, scan.rs:331-336: vacuum's skip set is traversed but not counted */
     }
     hitem c;
     while (heap_pop(&C, &c)) {
@@ -847,6 +850,7 @@ static int search_layer_scan(orc_scan *s, const hitem *ep, int nep, int ef, int 
             visited[e] = 1;
             int always_add = w_len < ef;
             f_dist = W.len ? W.d[0].dist : DBL_MAX;
+            if (x->el[e].deleted) continue;               /* load_element: deleted tuple -> None (scan.rs:178-181) */
             double d = dist_scan(s, e);
             if (!always_add && d >= f_dist) {       /* load_element returned None (scan.rs:195-200) */
                 if (discarded) {                    /* second load, scan.rs:385-404 (costs a 2nd distance) */
@@ -857,7 +861,8 @@ static int search_layer_scan(orc_scan *s, const hitem *ep, int nep, int ef, int 
             }
             if (x->el[e].level < layer) continue;
             hitem it = { d, e };
-            heap_push(&C, it); heap_push(&W, it); w_len++;
+            heap_push(&C, it); heap_push(&W, it);
+            if (!skip || !skip[e]) w_len++;                         /* scan.rs:416-419 */
             if (w_len > ef) { hitem ev; heap_pop(&W, &ev); w_len--; if (discarded) heap_push(discarded, ev); }
         }
     }
@@ -868,6 +873,12 @@ static int search_layer_scan(orc_scan *s, const hitem *ep, int nep, int ef, int 
     memcpy(*out, W.d, (size_t)n * sizeof(hitem));
     heap_free(&C); heap_free(&W); free(local);
     return n;
+}
+
+static int search_layer_scan(orc_scan *s, const hitem *ep, int nep, int ef, int layer,
+                             uint8_t *visited, heap_t *discarded, int add_entry_to_visited, hitem **out)
+{
+    return search_layer_scan_skip(s, ep, nep, ef, layer, visited, discarded, add_entry_to_visited, NULL, out);
 }
 
 /* get_scan_items scan.rs:458-530 */
@@ -955,6 +966,244 @@ ORC_API int orc_scan_next(orc_scan *s, int64_t *tid, double *dist, int *elem)
         s->cur = sc.idx; s->cur_tid_left = x->el[sc.idx].ntids; s->cur_dist = sc.dist;
     }
 }
+
+
+/* ------------------------------------------------------------------ */
+/* f3: the on-disk insert (aminsert, src/index/insert.rs) and vacuum's repair search (src/index/vacuum.rs:288-407)
+ * on the in-memory mirror: elements addressed by index instead of (blkno, offno), every distance through the scan
+ * path's f64 (scan.rs:190-191), no concurrency.                                                              */
+/* ------------------------------------------------------------------ */
+static inline double dist_elems(orc_index *x, int a, int b)
+{   /* FunctionCall2Coll(dist_fmgr, collation, datum(a), datum(b)): insert.rs:606, compute_element_distance :745-781 */
+    x->cnt[3]++;
+    return orc_distance(x->dtype, x->metric, x->dim, rowp(x, a), rowp(x, b), x->order);
+}
+
+/* find_element_neighbors_on_disk insert.rs:1021-1123.  out[lc] (malloc'd, nearest first), out_n[lc] for lc = 0..new_level.
+ * skip != NULL is vacuum's repair: ef + 1, skip-set members traversed but neither counted nor selected. */
+static void find_element_neighbors_on_disk(orc_scan *s, int new_level, int entry, const uint8_t *skip, hitem **out, int *out_n)
+{
+    orc_index *x = s->x;
+    for (int lc = 0; lc <= new_level; lc++) { out[lc] = NULL; out_n[lc] = 0; }
+    if (x->el[entry].deleted) return;                                  /* load_element(entry) -> None, insert.rs:1037-1048 */
+    int entry_level = x->el[entry].level, nep = 1;
+    hitem *epl = malloc(sizeof(hitem));
+    epl[0].dist = dist_scan(s, entry); epl[0].idx = entry;
+    for (int lc = entry_level; lc >= new_level + 1; lc--) {            /* phase 1, insert.rs:1053-1074 */
+        hitem *w; int nw = search_layer_scan_skip(s, epl, nep, 1, lc, NULL, NULL, 1, skip, &w);
+        free(epl);
+        if (nw == 0) { free(w); return; }
+        epl = malloc(sizeof(hitem)); epl[0] = w[nw - 1]; nep = 1; free(w);   /* w.into_iter().last(): the nearest */
+    }
+    int start = new_level < entry_level ? new_level : entry_level;
+    for (int lc = start; lc >= 0; lc--) {                              /* phase 2, insert.rs:1077-1120 */
+        int lm = layer_m(x->m, lc);
+        int ef = skip ? x->efc + 1 : x->efc;                           /* insert.rs:1081-1086 */
+        hitem *w; int nw = search_layer_scan_skip(s, epl, nep, ef, lc, NULL, NULL, 1, skip, &w);
+        out[lc] = malloc((size_t)(lm + 1) * sizeof(hitem));
+        int k = 0;
+        for (int i = nw - 1; i >= 0 && k < lm; i--) {                  /* filtered.iter().rev().take(lm): the lm nearest, NO heuristic */
+            if (skip && skip[w[i].idx]) continue;
+            out[lc][k++] = w[i];
+        }
+        out_n[lc] = k;
+        free(epl); epl = w; nep = nw;                                  /* ep_list = w (whole W, nearest last) */
+    }
+    free(epl);
+}
+
+/* get_update_index insert.rs:500-739.  Returns -3 = None, -2 = a free slot exists, >= 0 = slot to overwrite. */
+static int get_update_index(orc_index *x, int n, int layer, double new_distance)
+{
+    elem_t *ne = &x->el[n];
+    if (ne->deleted) return -3;                                        /* insert.rs:524-527 */
+    int lm = layer_m(x->m, layer), cnt = ne->ncnt[layer];
+    if (cnt < lm) return -2;                                           /* insert.rs:556-559 */
+    hitem *cand = malloc((size_t)(cnt + 1) * sizeof(hitem)); int nc = 0, pruned_deleted = -1;
+    for (int i = 0; i < cnt; i++) {                                    /* insert.rs:566-619 */
+        int c = ne->nbr[layer][i].idx;
+        if (x->el[c].deleted || x->el[c].ntids == 0) { if (pruned_deleted < 0) pruned_deleted = i; continue; }
+        cand[nc].dist = dist_elems(x, n, c); cand[nc].idx = c; nc++;
+    }
+    if (pruned_deleted >= 0) { free(cand); return pruned_deleted; }    /* insert.rs:622-625 */
+    stable_sort(cand, nc, 0);                                          /* insert.rs:630-634 */
+    cand[nc].dist = new_distance; cand[nc].idx = -1; nc++;             /* the new element, is_new */
+    stable_sort(cand, nc, 0);                                          /* insert.rs:661-665: ties keep existing elements first */
+    int *sel = malloc((size_t)nc * sizeof(int)), *pru = malloc((size_t)nc * sizeof(int)); int ns = 0, np = 0;
+    for (int h = 0; h < nc; h++) {                                     /* insert.rs:673-704 */
+        if (ns >= lm) break;
+        int closer = 1;
+        for (int k = 0; k < ns; k++) {
+            const hitem *hc = &cand[h], *sc = &cand[sel[k]];
+            if (hc->idx >= 0 && sc->idx >= 0) {                        /* pairs with the new element are not evaluated, insert.rs:680-693 */
+                double d = dist_elems(x, hc->idx, sc->idx);
+                if (d <= hc->dist) { closer = 0; break; }
+            }
+        }
+        if (closer) sel[ns++] = h; else pru[np++] = h;
+    }
+    for (int k = 0; k < np && ns < lm; k++) sel[ns++] = pru[k];        /* insert.rs:707-712 */
+    int new_selected = 0;
+    for (int k = 0; k < ns; k++) if (cand[sel[k]].idx < 0) new_selected = 1;
+    int replace = -3;
+    if (new_selected) {                                                /* insert.rs:722-737: first existing neighbour, in list order, that was not selected */
+        for (int i = 0; i < cnt && replace < 0; i++) {
+            int c = ne->nbr[layer][i].idx, found = 0;
+            for (int k = 0; k < ns; k++) if (cand[sel[k]].idx == c) { found = 1; break; }
+            if (!found) replace = i;
+        }
+    }
+    free(cand); free(sel); free(pru);
+    return replace;
+}
+
+/* write_neighbor_update insert.rs:793-871 */
+static void write_neighbor_update(orc_index *x, int n, int layer, int new_idx, double new_distance, int update_idx)
+{
+    elem_t *ne = &x->el[n];
+    int lm = layer_m(x->m, layer), cnt = ne->ncnt[layer];
+    for (int i = 0; i < cnt; i++) if (ne->nbr[layer][i].idx == new_idx) return;      /* connection already exists */
+    cand_t nc = { (float)new_distance, new_idx };
+    if (update_idx == -2) { if (cnt < lm) { ne->nbr[layer][cnt] = nc; ne->ncnt[layer] = cnt + 1; } }
+    else if (update_idx >= 0 && update_idx < cnt) ne->nbr[layer][update_idx] = nc;
+}
+
+/* aminsert insert.rs:1227-1480 for one row.  Returns the element that holds the tid. */
+ORC_API int orc_index_insert_on_disk(orc_index *x, const void *row, int level, int64_t tid)
+{
+    if (level > x->max_level) level = x->max_level;
+    if (x->entry < 0) {
+        int e = push_element(x, row, level);
+        x->el[e].tids[0] = tid; x->el[e].ntids = 1; x->entry = e; x->ind_tuples += 1.0;
+        return e;
+    }
+    orc_scan s; memset(&s, 0, sizeof s);
+    s.x = x; s.q = malloc(x->row_bytes); memcpy(s.q, row, x->row_bytes);
+    int entry = x->entry, entry_level = x->el[entry].level;
+    hitem **nb = malloc((size_t)(level + 1) * sizeof(hitem *)); int *nn = malloc((size_t)(level + 1) * sizeof(int));
+    find_element_neighbors_on_disk(&s, level, entry, NULL, nb, nn);
+    int result = -1;
+    for (int k = 0; k < nn[0]; k++) {                                  /* find_duplicate_on_disk insert.rs:1180-1214 */
+        if (nb[0][k].dist != 0.0) break;
+        int c = nb[0][k].idx;
+        if (memcmp(row, rowp(x, c), x->row_bytes) == 0 && x->el[c].ntids > 0 && x->el[c].ntids < HNSW_HEAPTIDS) {   /* add_duplicate_on_disk :1136-1171 */
+            x->el[c].tids[x->el[c].ntids++] = tid; result = c; break;
+        }
+    }
+    if (result >= 0 && x->ondisk_tombstones) {          /* test convention shared with the engine: element index == row index, so a merged row leaves a tombstone */
+        int e = push_element(x, row, level); x->el[e].merged = 1; x->el[e].ntids = 0;
+    }
+    if (result < 0) {
+        int e = push_element(x, row, level);
+        for (int lc = 0; lc <= level; lc++) {
+            int lm = layer_m(x->m, lc), c = nn[lc] < lm ? nn[lc] : lm;
+            for (int i = 0; i < c; i++) { x->el[e].nbr[lc][i].distance = (float)nb[lc][i].dist; x->el[e].nbr[lc][i].idx = nb[lc][i].idx; }
+            x->el[e].ncnt[lc] = c;
+        }
+        x->el[e].tids[0] = tid; x->el[e].ntids = 1;
+        for (int lc = level; lc >= 0; lc--) {                          /* update_neighbors_on_disk insert.rs:883-958 */
+            int lm = layer_m(x->m, lc);
+            for (int k = 0; k < nn[lc] && k < lm; k++) {
+                int n = nb[lc][k].idx;
+                if (x->el[n].deleted) continue;                        /* load_element -> None */
+                int ui = get_update_index(x, n, lc, nb[lc][k].dist);
+                if (ui == -3) continue;
+                write_neighbor_update(x, n, lc, e, nb[lc][k].dist, ui);
+            }
+        }
+        if (level > entry_level) x->entry = e;                         /* insert.rs:1453-1470 */
+        result = e;
+    }
+    x->ind_tuples += 1.0;
+    for (int lc = 0; lc <= level; lc++) free(nb[lc]);
+    free(nb); free(nn); free(s.q);
+    return result;
+}
+
+/* repair_graph_element vacuum.rs:288-407: new neighbours of element e found with the deleted set (+ e itself) skipped */
+ORC_API void orc_index_repair_element(orc_index *x, int e, const uint8_t *deleted)
+{
+    if (e == x->entry) return;                                         /* vacuum.rs:300-303 */
+    uint8_t *skip = malloc((size_t)x->n);
+    for (int i = 0; i < x->n; i++) skip[i] = deleted ? deleted[i] : 0;
+    skip[e] = 1;
+    orc_scan s; memset(&s, 0, sizeof s);
+    s.x = x; s.q = malloc(x->row_bytes); memcpy(s.q, rowp(x, e), x->row_bytes);
+    int level = x->el[e].level;
+    hitem **nb = malloc((size_t)(level + 1) * sizeof(hitem *)); int *nn = malloc((size_t)(level + 1) * sizeof(int));
+    find_element_neighbors_on_disk(&s, level, x->entry, skip, nb, nn);
+    for (int lc = 0; lc <= level; lc++) {                              /* vacuum.rs:358-373: the tuple is rebuilt from scratch */
+        int lm = layer_m(x->m, lc), c = nn[lc] < lm ? nn[lc] : lm;
+        for (int i = 0; i < c; i++) { x->el[e].nbr[lc][i].distance = (float)nb[lc][i].dist; x->el[e].nbr[lc][i].idx = nb[lc][i].idx; }
+        x->el[e].ncnt[lc] = c;
+        free(nb[lc]);
+    }
+    free(nb); free(nn); free(s.q); free(skip);
+}
+ORC_API void orc_index_mark_deleted(orc_index *x, int e, int flag) { x->el[e].deleted = flag; }
+ORC_API void orc_index_clear_tids(orc_index *x, int e) { x->el[e].ntids = 0; }      /* remove_heap_tids vacuum.rs:118-217 removed every TID */
+
+/* ---- vacuum (src/index/vacuum.rs): pass 1 remove_heap_tids :118-217, pass 2 repair_graph :411-644 (needs_updated :230-285,
+ * repair_graph_entry_point :411-520, repair_graph_element :288-407), pass 3 mark_deleted :655-793 -- on the in-memory mirror.
+ * dead: the heap TIDs the bulk-delete callback reports dead (any order). ---- */
+static int cmp_i64(const void *a, const void *b) { int64_t x = *(const int64_t *)a, y = *(const int64_t *)b; return x < y ? -1 : x > y; }
+static int needs_updated(orc_index *x, int e, const uint8_t *deleted)
+{
+    elem_t *el = &x->el[e];
+    for (int lc = 0; lc <= el->level; lc++)
+        for (int k = 0; k < el->ncnt[lc]; k++) if (deleted[el->nbr[lc][k].idx]) return 1;
+    return el->ncnt[0] < layer_m(x->m, 0);                              /* "also update if layer 0 is not full", vacuum.rs:268-279 */
+}
+/* repair_graph_element with an explicit entry (the entry-point repair passes the highest point instead), vacuum.rs:288-407 */
+static void repair_element_from(orc_index *x, int e, int entry, const uint8_t *deleted)
+{
+    if (e == entry || entry < 0) return;
+    int saved = x->entry; x->entry = entry;
+    orc_index_repair_element(x, e, deleted);
+    x->entry = saved;
+}
+ORC_API void orc_index_vacuum(orc_index *x, const int64_t *dead, int n_dead)
+{
+    int64_t *ds = malloc((size_t)(n_dead + 1) * sizeof(int64_t));
+    memcpy(ds, dead, (size_t)n_dead * sizeof(int64_t)); qsort(ds, (size_t)n_dead, sizeof(int64_t), cmp_i64);
+    uint8_t *deleted = calloc((size_t)x->n + 1, 1);
+    int highest = -1, highest_level = -1;
+    for (int e = 0; e < x->n; e++) {                                     /* pass 1 */
+        elem_t *el = &x->el[e];
+        if (el->merged) continue;                                        /* batch-schedule tombstone: has no tuple */
+        if (el->ntids > 0) {
+            int k = 0;
+            for (int i = 0; i < el->ntids; i++) if (!bsearch(&el->tids[i], ds, (size_t)n_dead, sizeof(int64_t), cmp_i64)) el->tids[k++] = el->tids[i];
+            el->ntids = k;
+        }
+        if (el->ntids == 0) deleted[e] = 1;
+        else if (el->level > highest_level && e != x->entry) { highest = e; highest_level = el->level; }
+    }
+    /* pass 2: entry point first (vacuum.rs:411-520) */
+    if (highest >= 0 && !x->el[highest].deleted && needs_updated(x, highest, deleted)) repair_element_from(x, highest, x->entry, deleted);
+    if (x->entry >= 0) {
+        if (deleted[x->entry]) x->entry = highest;                       /* -1 when nothing is left */
+        else if (!x->el[x->entry].deleted && needs_updated(x, x->entry, deleted)) repair_element_from(x, x->entry, highest >= 0 ? highest : x->entry, deleted);
+    }
+    for (int e = 0; e < x->n; e++) {                                     /* then every element that still holds a heap TID (vacuum.rs:540-640) */
+        elem_t *el = &x->el[e];
+        if (el->merged || el->ntids == 0 || el->deleted) continue;
+        if (!needs_updated(x, e, deleted)) continue;
+        if (x->entry < 0 || el->level > x->el[x->entry].level) {
+            repair_element_from(x, e, x->entry, deleted);
+            if (x->entry < 0 || el->level > x->el[x->entry].level) x->entry = e;
+        } else repair_element_from(x, e, x->entry, deleted);
+    }
+    for (int e = 0; e < x->n; e++) {                                     /* pass 3 */
+        elem_t *el = &x->el[e];
+        if (el->merged || el->deleted || el->ntids > 0) continue;
+        for (int lc = 0; lc <= el->level; lc++) el->ncnt[lc] = 0;
+        el->deleted = 1;
+    }
+    free(ds); free(deleted);
+}
+ORC_API int orc_index_deleted(const orc_index *x, int e) { return x->el[e].deleted; }
+ORC_API void orc_index_set_ondisk_tombstones(orc_index *x, int on) { x->ondisk_tombstones = on; }
 
 /* convenience: non-iterative top-k of one query -> element ids + f64 distances; returns count */
 ORC_API int orc_search_topk(orc_index *x, const void *query, int ef_search, int k, int *ids, double *dist)

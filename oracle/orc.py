@@ -76,6 +76,13 @@ def lib():
             "orc_bruteforce_topk": (i32, [vp, vp, i32, vp, vp]),
             "orc_distances_many": (None, [i32, i32, i32, vp, vp, vp, i32, i32, vp]),
             "orc_pairwise": (None, [i32, i32, i32, vp, vp, i32, i32, vp]),
+            "orc_index_insert_on_disk": (i32, [vp, vp, i32, i64]),
+            "orc_index_repair_element": (None, [vp, i32, vp]),
+            "orc_index_mark_deleted": (None, [vp, i32, i32]),
+            "orc_index_clear_tids": (None, [vp, i32]),
+            "orc_index_vacuum": (None, [vp, vp, i32]),
+            "orc_index_deleted": (i32, [vp, i32]),
+            "orc_index_set_ondisk_tombstones": (None, [vp, i32]),
             "orc_acc_w64_plain": (f32, [i32, i32, i32, vp, vp]),
             "orc_acc_w64_fast": (f32, [i32, i32, i32, vp, vp]),
         }
@@ -154,6 +161,34 @@ class Index:
         row = as_rows(self.dtype, row)
         assert row.nbytes == self.row_bytes
         return lib().orc_index_insert(self.h, _p(row), int(level), int(tid))
+
+    def set_ondisk_tombstones(self, on=True):
+        lib().orc_index_set_ondisk_tombstones(self.h, int(on))
+
+    def insert_on_disk(self, row, level, tid):
+        """aminsert (insert.rs:1227-1480) on the in-memory mirror."""
+        row = as_rows(self.dtype, row)
+        assert row.nbytes == self.row_bytes
+        return lib().orc_index_insert_on_disk(self.h, _p(row), int(level), int(tid))
+
+    def repair_element(self, e, deleted=None):
+        """repair_graph_element (vacuum.rs:288-407): deleted = uint8 flags per element (the vacuum's deleted set)."""
+        d = None if deleted is None else np.ascontiguousarray(deleted, np.uint8)
+        lib().orc_index_repair_element(self.h, int(e), None if d is None else _p(d))
+
+    def vacuum(self, dead_tids):
+        """ambulkdelete + amvacuumcleanup (vacuum.rs): dead_tids = heap TIDs reported dead."""
+        d = np.ascontiguousarray(dead_tids, np.int64)
+        lib().orc_index_vacuum(self.h, _p(d), len(d))
+
+    def deleted(self, e):
+        return lib().orc_index_deleted(self.h, int(e))
+
+    def mark_deleted(self, e, flag=1):
+        lib().orc_index_mark_deleted(self.h, int(e), int(flag))
+
+    def clear_tids(self, e):
+        lib().orc_index_clear_tids(self.h, int(e))
 
     def insert_batch(self, rows, levels, tids):
         rows = as_rows(self.dtype, rows)

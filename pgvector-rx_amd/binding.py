@@ -73,6 +73,9 @@ def lib():
         "hx_index_batch_export_links": (i32, [vp, vp]),
         "hx_index_batch_import_links": (i32, [vp, vp, u64]),
         "hx_index_batch_end": (i32, [vp, vp]),
+        "hx_index_insert_ondisk": (i32, [vp, u64, u32, vp, vp, u32, vp]),
+        "hx_index_vacuum": (i32, [vp, vp, u64, u32, C.POINTER(u64), C.POINTER(u64)]),
+        "hx_index_deleted": (i32, [vp, u32]),
         "hx_index_dbatch_supported": (i32, [vp, vp, u32]),
         "hx_index_dbatch_record_bytes": (u64, [vp]),
         "hx_index_dbatch_list_record_bytes": (u64, [vp]),
@@ -276,6 +279,25 @@ class Index:
         out = np.empty(n, np.uint32)
         self._ck(lib().hx_index_insert(self.h, first_row, n, _p(levels), _p(tids), batch, _p(out)))
         return out
+
+    def insert_ondisk(self, first_row, levels, tids=None, batch=1):
+        """aminsert (insert.rs:1227-1480) for rows already appended to the engine."""
+        levels = np.ascontiguousarray(levels, np.int32)
+        n = len(levels)
+        tids = np.arange(first_row, first_row + n, dtype=np.int64) if tids is None else np.ascontiguousarray(tids, np.int64)
+        out = np.empty(n, np.uint32)
+        self._ck(lib().hx_index_insert_ondisk(self.h, first_row, n, _p(levels), _p(tids), batch, _p(out)))
+        return out
+
+    def vacuum(self, dead_tids, batch=1):
+        """ambulkdelete + amvacuumcleanup (vacuum.rs); returns (elements marked deleted, elements repaired)."""
+        d = np.ascontiguousarray(dead_tids, np.int64)
+        nd, nr = C.c_uint64(0), C.c_uint64(0)
+        self._ck(lib().hx_index_vacuum(self.h, _p(d), len(d), batch, C.byref(nd), C.byref(nr)))
+        return nd.value, nr.value
+
+    def deleted(self, e):
+        return lib().hx_index_deleted(self.h, e)
 
     # ---- staged batch (multi-GPU build; see dist_build.py) ----
     def batch_begin(self, first_row, levels, tids):

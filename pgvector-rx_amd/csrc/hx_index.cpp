@@ -132,13 +132,14 @@ struct Graph {
     std::vector<Cand> up; std::vector<uint16_t> up_cnt;              // up: stride m per layer; up_cnt per (elem, layer)
     std::vector<uint64_t> upc_off;
     std::vector<std::array<int64_t, HEAPTIDS>> tids; std::vector<uint8_t> ntids;
+    std::vector<uint8_t> deleted;           // HnswElementTupleData.deleted (types/hnsw.rs:112-137): set by vacuum's mark_deleted
     int64_t entry = -1;
 
     uint32_t size() const { return (uint32_t)level.size(); }
     void reserve(size_t n)      // no reallocation (and re-copy of gigabytes) while a bulk insert appends n more elements
     {
         const size_t t = level.size() + n;
-        level.reserve(t); n0_cnt.reserve(t); n0.reserve(t * 2 * (size_t)m); up_off.reserve(t); upc_off.reserve(t); tids.reserve(t); ntids.reserve(t);
+        level.reserve(t); deleted.reserve(t); n0_cnt.reserve(t); n0.reserve(t * 2 * (size_t)m); up_off.reserve(t); upc_off.reserve(t); tids.reserve(t); ntids.reserve(t);
         up.reserve(up.size() + n / 8 * (size_t)m + 64); up_cnt.reserve(up_cnt.size() + n / 8 + 64);
     }
     int lm(int layer) const { return layer == 0 ? 2 * m : m; }       // hnsw_get_layer_m, hnsw_constants.rs:122-128
@@ -149,7 +150,7 @@ struct Graph {
         n0_cnt.push_back(0); n0.resize(n0.size() + 2 * (size_t)m);
         up_off.push_back(up.size()); upc_off.push_back(up_cnt.size());
         if (lv > 0) { up.resize(up.size() + (size_t)lv * m); up_cnt.resize(up_cnt.size() + lv, 0); }
-        tids.emplace_back(); ntids.push_back(0);
+        tids.emplace_back(); ntids.push_back(0); deleted.push_back(0);
         return id;
     }
     Cand *list(uint32_t e, int layer) { return layer == 0 ? &n0[(size_t)e * 2 * m] : &up[up_off[e] + (size_t)(layer - 1) * m]; }
@@ -194,6 +195,10 @@ struct SearchCore {
     RHeap<true> *discarded = nullptr;
     std::vector<uint32_t> pend;
     bool finished = true;
+    // vacuum's repair search (search_layer_disk's skip_count, scan.rs:331-336,416-419): members of `skip` and `skip_self` are traversed and kept in W
+    // but do not count towards ef; elements flagged in `deleted` are visited and dropped (load_element -> None, scan.rs:178-181)
+    const uint8_t *skip = nullptr, *deleted = nullptr; uint32_t skip_self = 0xFFFFFFFFu;
+    inline bool counted(uint32_t e) const { return e != skip_self && !(skip && skip[e]); }
 
     void start(const Graph *gr, const std::vector<Cand> &ep, size_t ef_, int layer_, bool scan, VisitedSet *shared_vis,
                RHeap<true> *disc, bool add_entry_to_visited)
@@ -203,7 +208,7 @@ struct SearchCore {
         if (shared_vis) vis = shared_vis; else { own_vis.reset(ef * 8 + 64); vis = &own_vis; }
         for (const Cand &e : ep) {
             if (add_entry_to_visited) vis->test_and_set(e.id);
-            C.push(e); W.push(e); wlen++;
+            C.push(e); W.push(e); if (counted(e.id)) wlen++;
         }
     }
     inline void apply(uint32_t e, float d)
@@ -214,7 +219,7 @@ struct SearchCore {
         else { const double f = W.empty() ? DBL_MAX : (double)W.top().d; add = !(!always_add && (double)d >= f); } // scan.rs:372-383,195-200
         if (add) {
             Cand c{d, e};
-            C.push(c); W.push(c); wlen++;
+            C.push(c); W.push(c); if (counted(e)) wlen++;
             if (wlen > ef) { Cand ev; W.pop(ev); wlen--; if (discarded) discarded->push(ev); }   // mod.rs:239-242 / scan.rs:420-429
         } else if (discarded) {
             discarded->push(Cand{d, e});                                                        // scan.rs:385-404
@@ -233,6 +238,7 @@ struct SearchCore {
             for (uint16_t k = 0; k < n; k++) {
                 const uint32_t e = nb[k].id;
                 if (vis->test_and_set(e)) continue;                                  // mod.rs:206-209
+                if (deleted && deleted[e]) continue;
                 if (layer > 0 && g->level[e] < layer) continue;                      // mod.rs:213-216; at layer 0 every linked element qualifies (tombstones are never linked)
                 pend.push_back(e);
             }
@@ -499,6 +505,134 @@ struct QueryTask : LsTask {
     }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// f3: the on-disk paths.  find_element_neighbors_on_disk (src/index/insert.rs:1021-1123): Algorithm 1 over search_layer_disk
+// (f64 comparisons, nearest-last results), the `lm` NEAREST of each layer taken WITHOUT the heuristic (:1111-1117); with a skip
+// set (vacuum's repair, src/index/vacuum.rs:288-407) ef + 1 and skip members neither counted nor selected.
+// ------------------------------------------------------------------------------------------------
+struct DiskNeighborsTask : LsTask {
+    const Graph *g; uint32_t query_sel = 0; int new_level = 0, entry_level = 0; uint32_t entry = 0; int efc = 64;
+    const uint8_t *skip = nullptr; uint32_t skip_self = 0xFFFFFFFFu; bool repair = false;
+    enum { S_INIT, S_ENTRY, S_GREEDY, S_SEARCH, S_DONE } st = S_INIT;
+    int lc = 0;
+    std::vector<Cand> ep, w;
+    SearchCore sc;
+    std::vector<std::vector<Cand>> nb;     // per layer, nearest first
+    void reset() { st = S_INIT; lc = 0; n_dist = n_pair = 0; clear_req(); ep.clear(); w.clear(); }
+    void begin_search(size_t ef, int layer)
+    {
+        sc.skip = skip; sc.skip_self = skip_self; sc.deleted = g->deleted.data();
+        sc.start(g, ep, ef, layer, true, nullptr, nullptr, true);
+    }
+    bool post_search() { dist_ids = sc.pend; q_sel = query_sel; n_dist += dist_ids.size(); return true; }
+    bool advance(const float *dres, const float *) override
+    {
+        clear_req();
+        for (;;) {
+            switch (st) {
+            case S_INIT:
+                nb.assign(new_level + 1, {});
+                if (g->deleted[entry]) { st = S_DONE; break; }                       // load_element(entry) -> None, insert.rs:1037-1048
+                dist_ids.push_back(entry); q_sel = query_sel; n_dist += 1; st = S_ENTRY;
+                return true;
+            case S_ENTRY:
+                ep.assign(1, Cand{dres[0], entry}); dres = nullptr;
+                lc = entry_level; st = S_GREEDY;
+                if (lc >= new_level + 1) begin_search(1, lc);
+                break;
+            case S_GREEDY:                                                           // insert.rs:1053-1074
+                if (lc < new_level + 1) {
+                    lc = std::min(new_level, entry_level); st = S_SEARCH;
+                    if (lc >= 0) begin_search((size_t)efc + (repair ? 1 : 0), lc);   // insert.rs:1081-1086
+                    break;
+                }
+                if (sc.run(dres)) return post_search();
+                dres = nullptr;
+                sc.results_desc(w);
+                if (w.empty()) { st = S_DONE; break; }
+                ep.assign(1, w.back());                                              // w.into_iter().last(): the nearest
+                lc--;
+                if (lc >= new_level + 1) begin_search(1, lc);
+                break;
+            case S_SEARCH:                                                           // insert.rs:1077-1120
+                if (lc < 0) { st = S_DONE; break; }
+                if (sc.run(dres)) return post_search();
+                dres = nullptr;
+                sc.results_desc(w);
+                {
+                    const size_t lm = (size_t)g->lm(lc);
+                    std::vector<Cand> &out = nb[lc];
+                    for (size_t i = w.size(); i-- > 0 && out.size() < lm;) {         // filtered.iter().rev().take(lm)
+                        if (w[i].id == skip_self || (skip && skip[w[i].id])) continue;
+                        out.push_back(w[i]);
+                    }
+                }
+                ep = w;                                                              // ep_list = w
+                lc--;
+                if (lc >= 0) begin_search((size_t)efc + (repair ? 1 : 0), lc);
+                break;
+            case S_DONE:
+                return false;
+            }
+        }
+    }
+};
+
+// get_update_index (insert.rs:500-739) for one (neighbour element, layer): where the new element goes in that list, if anywhere.
+// One request: d(neighbour, each connected element) as a distance group and the pair block among the connected elements.
+struct UpdateIndexTask : LsTask {
+    const Graph *g; uint32_t nbr = 0; int layer = 0; float new_d = 0.0f;
+    int result = -3;                       // -3 None, -2 free slot, >= 0 slot to overwrite
+    std::vector<uint32_t> ids;
+    int stage = 0;
+    void reset() { stage = 0; result = -3; n_dist = n_pair = 0; clear_req(); ids.clear(); }
+    bool advance(const float *dres, const float *pres) override
+    {
+        clear_req();
+        const size_t lm = (size_t)g->lm(layer);
+        if (stage == 0) {
+            stage = 1;
+            if (g->deleted[nbr]) { result = -3; return false; }                     // insert.rs:524-527
+            const Cand *lst = g->list(nbr, layer); const size_t cnt = g->cnt(nbr, layer);
+            if (cnt < lm) { result = -2; return false; }                            // insert.rs:556-559
+            for (size_t i = 0; i < cnt; i++) {                                      // insert.rs:566-625: an element being deleted gives up its slot
+                const uint32_t c = lst[i].id;
+                if (g->deleted[c] || g->ntids[c] == 0) { result = (int)i; return false; }
+            }
+            ids.resize(cnt);
+            for (size_t i = 0; i < cnt; i++) ids[i] = lst[i].id;
+            dist_ids = ids; q_sel = nbr; n_dist += cnt;
+            if (cnt >= 2) { pgroups.push_back(PairGroup{(uint16_t)cnt, 0}); pair_ids = ids; n_pair += cnt * (cnt - 1) / 2; }
+            return true;
+        }
+        // candidates sorted by distance (stable), then the new element added and sorted again (stable): insert.rs:630-665
+        const size_t cnt = ids.size();
+        struct HC { float d; int slot; };                                           // slot -1 = the new element
+        std::vector<HC> all(cnt);
+        for (size_t i = 0; i < cnt; i++) all[i] = HC{dres[i], (int)i};
+        std::stable_sort(all.begin(), all.end(), [](const HC &a, const HC &b) { return a.d < b.d; });
+        all.push_back(HC{new_d, -1});
+        std::stable_sort(all.begin(), all.end(), [](const HC &a, const HC &b) { return a.d < b.d; });
+        auto pair_d = [&](int a, int b) { const int hi = a > b ? a : b, lo = a > b ? b : a; return pres[(size_t)hi * (hi - 1) / 2 + lo]; };
+        std::vector<int> sel, pruned;                                               // indices into `all`
+        for (size_t h = 0; h < all.size(); h++) {                                   // insert.rs:673-704
+            if (sel.size() >= lm) break;
+            bool closer = true;
+            for (int k : sel) {
+                if (all[h].slot >= 0 && all[k].slot >= 0 && pair_d(all[h].slot, all[k].slot) <= all[h].d) { closer = false; break; }   // pairs with the new element are skipped (:680-693)
+            }
+            if (closer) sel.push_back((int)h); else pruned.push_back((int)h);
+        }
+        for (int k : pruned) { if (sel.size() >= lm) break; sel.push_back(k); }    // insert.rs:707-712
+        bool new_selected = false; std::vector<uint8_t> kept(cnt, 0);
+        for (int k : sel) { if (all[k].slot < 0) new_selected = true; else kept[all[k].slot] = 1; }
+        result = -3;
+        if (new_selected) for (size_t i = 0; i < cnt; i++) if (!kept[i]) { result = (int)i; break; }   // insert.rs:722-737
+        return false;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // tiny persistent thread pool: parallel_for over task indices
 // ------------------------------------------------------------------------------------------------
@@ -566,6 +700,8 @@ struct hx_index {
     std::vector<std::unique_ptr<InsertTask>> insert_pool;      // task objects are reused across batches (their heaps,
     std::vector<std::unique_ptr<BacklinkTask>> backlink_pool;  // visited tables and request vectors keep their capacity)
     std::vector<std::unique_ptr<QueryTask>> query_pool;
+    std::vector<std::unique_ptr<DiskNeighborsTask>> disk_pool;
+    std::vector<std::unique_ptr<UpdateIndexTask>> update_pool;
     bool fused = true;                                         // device-resident traversal (hx_fused.inc.h) for searches
     std::vector<std::pair<uint32_t, int>> dirty;               // (element, layer) lists the device mirror has not seen yet
     uint32_t mirror_elems = 0;
@@ -671,7 +807,7 @@ struct hx_index {
             if (!bs.linked && g.size() > keep) {
                 g.level.resize(keep); g.n0_cnt.resize(keep); g.n0.resize((size_t)keep * 2 * g.m);
                 g.up.resize(g.up_off[keep]); g.up_cnt.resize(g.upc_off[keep]); g.up_off.resize(keep); g.upc_off.resize(keep);
-                g.tids.resize(keep); g.ntids.resize(keep);
+                g.tids.resize(keep); g.ntids.resize(keep); g.deleted.resize(keep);
                 if (mirror_elems > keep) mirror_elems = keep;
                 size_t w = 0; for (size_t k = 0; k < dirty.size(); k++) if (dirty[k].first < keep) dirty[w++] = dirty[k]; dirty.resize(w);
             }
@@ -1436,6 +1572,212 @@ int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t 
     }
     return HX_OK;
 }
+
+
+// ================================================================================================
+// f3: aminsert (src/index/insert.rs:1227-1480) and vacuum (src/index/vacuum.rs) on the engine
+// ================================================================================================
+namespace {
+// write_neighbor_update insert.rs:793-871
+void write_neighbor_update(hx_index *ix, uint32_t n, int layer, uint32_t new_id, float new_d, int update_idx)
+{
+    Graph &g = ix->g;
+    Cand *lst = g.list(n, layer); uint16_t &cnt = g.cnt(n, layer); const int lm = g.lm(layer);
+    for (uint16_t i = 0; i < cnt; i++) if (lst[i].id == new_id) return;            // connection already exists
+    if (update_idx == -2) { if (cnt < lm) { lst[cnt++] = Cand{new_d, new_id}; ix->dirty.emplace_back(n, layer); } }
+    else if (update_idx >= 0 && update_idx < (int)cnt) { lst[update_idx] = Cand{new_d, new_id}; ix->dirty.emplace_back(n, layer); }
+}
+}  // namespace
+
+int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids, uint32_t batch, uint32_t *elem_out)
+{
+    if (!ix) return HX_E_ARG;
+    if (n == 0) return HX_OK;
+    if (!levels || !tids) return ix->fail(HX_E_ARG, "NULL argument");
+    Graph &g = ix->g;
+    if (ix->bs.open) return ix->fail(HX_E_STATE, "a staged batch is open");
+    if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
+    if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
+    if (2 * g.m > (int)HX_PAIR_MAX_ROWS) return ix->fail(HX_E_ARG, "the on-disk insert path serves m <= 32");
+    if (batch == 0) batch = 1;
+    int rc = ix->ensure_host_lists();
+    if (rc) return rc;
+    const int mxl = max_level_for(g.m);
+    uint32_t done = 0;
+    while (done < n) {
+        if (g.entry < 0) {                                                          // first element: insert.rs:1320-1338 (no entry point yet)
+            int lv = std::min(levels[done], mxl); if (lv < 0) lv = 0;
+            const uint32_t id = g.add(lv);
+            g.entry = id; g.tids[id][0] = tids[done]; g.ntids[id] = 1;
+            if (elem_out) elem_out[done] = id;
+            done++;
+            continue;
+        }
+        const uint32_t b = std::min(batch, n - done), base = g.size();
+        const uint32_t entry = (uint32_t)g.entry; const int entry_level = g.level[entry];
+        // stage 1: every member's neighbour search against the graph as it stands (batch == 1: the reference's one insert at a time;
+        // batch > 1: what concurrent backends do -- each searches without seeing the others' uncommitted elements, e.g. 013's 10 pgbench clients)
+        auto &dts = ix->disk_pool;
+        while (dts.size() < b) dts.emplace_back(new DiskNeighborsTask());
+        std::vector<LsTask *> tasks(b);
+        for (uint32_t i = 0; i < b; i++) {
+            DiskNeighborsTask &t = *dts[i];
+            t.reset();
+            int lv = std::min(levels[done + i], mxl); if (lv < 0) lv = 0;
+            t.g = &g; t.query_sel = base + i; t.new_level = lv; t.entry = entry; t.entry_level = entry_level; t.efc = ix->efc;
+            t.skip = nullptr; t.skip_self = 0xFFFFFFFFu; t.repair = false;
+            tasks[i] = &t;
+        }
+        if ((rc = ix->run_lockstep(tasks))) return rc;
+        // duplicate candidates: leading zero-distance layer-0 neighbours, compared byte for byte (find_duplicate_on_disk insert.rs:1180-1214)
+        std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0u);
+        for (uint32_t i = 0; i < b; i++) {
+            const DiskNeighborsTask &t = *dts[i];
+            if (!t.nb.empty()) for (const Cand &c : t.nb[0]) { if (c.d != 0.0f) break; da.push_back(base + i); db.push_back(c.id); }
+            dstart[i + 1] = (uint32_t)da.size();
+        }
+        std::vector<uint8_t> deq(da.size(), 0);
+        if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
+        // stage 2: members in order -- duplicate merge, or element + back-connections
+        for (uint32_t i = 0; i < b; i++) {
+            DiskNeighborsTask &t = *dts[i];
+            ix->counters[4] += t.n_dist;
+            const uint32_t id = g.add(t.new_level);                                 // element id == row id, also for a merged row (tombstone)
+            int64_t dup = -1;
+            for (uint32_t k = dstart[i]; k < dstart[i + 1]; k++)
+                if (deq[k] && g.ntids[db[k]] > 0 && g.ntids[db[k]] < HEAPTIDS && !g.deleted[db[k]]) { dup = db[k]; break; }   // add_duplicate_on_disk :1136-1171
+            if (dup >= 0) {
+                g.tids[dup][g.ntids[dup]++] = tids[done + i];
+                g.level[id] = -1 - g.level[id];
+                if (elem_out) elem_out[done + i] = (uint32_t)dup;
+                continue;
+            }
+            for (int lc = 0; lc <= t.new_level; lc++) {                             // the new element's neighbour tuple, insert.rs:1384-1410
+                Cand *lst = g.list(id, lc); const size_t c = std::min(t.nb[lc].size(), (size_t)g.lm(lc));
+                for (size_t k = 0; k < c; k++) lst[k] = t.nb[lc][k];
+                g.cnt(id, lc) = (uint16_t)c;
+            }
+            g.tids[id][0] = tids[done + i]; g.ntids[id] = 1;
+            ix->mark_dirty(id);
+            // update_neighbors_on_disk insert.rs:883-958: one get_update_index per (neighbour, layer); distinct lists, so they run in lock-step
+            auto &uts = ix->update_pool; std::vector<LsTask *> utasks;
+            size_t nu = 0;
+            for (int lc = t.new_level; lc >= 0; lc--) {
+                const size_t lm = (size_t)g.lm(lc);
+                for (size_t k = 0; k < t.nb[lc].size() && k < lm; k++) {
+                    if (nu == uts.size()) uts.emplace_back(new UpdateIndexTask());
+                    UpdateIndexTask &u = *uts[nu++];
+                    u.reset(); u.g = &g; u.nbr = t.nb[lc][k].id; u.layer = lc; u.new_d = t.nb[lc][k].d;
+                    utasks.push_back(&u);
+                }
+            }
+            if ((rc = ix->run_lockstep(utasks))) return rc;
+            for (size_t k = 0; k < nu; k++) {
+                UpdateIndexTask &u = *uts[k];
+                ix->counters[3] += u.n_dist + u.n_pair;
+                if (u.result == -3) continue;
+                write_neighbor_update(ix, u.nbr, u.layer, id, u.new_d, u.result);
+            }
+            if (t.new_level > g.level[g.entry]) g.entry = id;                       // insert.rs:1453-1470 (HNSW_UPDATE_ENTRY_GREATER)
+            if (elem_out) elem_out[done + i] = id;
+        }
+        done += b;
+    }
+    return HX_OK;
+}
+
+// vacuum.rs: pass 1 remove_heap_tids, pass 2 repair_graph, pass 3 mark_deleted.  batch == 1: elements are repaired one after the other as the
+// reference does; batch > 1: that many repair searches run in lock-step against the same state of the graph.
+int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uint32_t batch, uint64_t *n_deleted_out, uint64_t *n_repaired_out)
+{
+    if (!ix || (!dead_tids && n_dead)) return HX_E_ARG;
+    Graph &g = ix->g;
+    if (ix->bs.open) return ix->fail(HX_E_STATE, "a staged batch is open");
+    if (batch == 0) batch = 1;
+    int rc = ix->ensure_host_lists();
+    if (rc) return rc;
+    std::vector<int64_t> dead(dead_tids, dead_tids + n_dead);
+    std::sort(dead.begin(), dead.end());
+    const uint32_t n = g.size();
+    std::vector<uint8_t> del(n, 0);
+    int64_t highest = -1; int highest_level = -1;
+    for (uint32_t e = 0; e < n; e++) {                                              // pass 1, vacuum.rs:118-217
+        if (g.level[e] < 0) continue;                                               // merged duplicate: has no tuple
+        if (g.ntids[e] > 0) {
+            uint8_t k = 0;
+            for (uint8_t i = 0; i < g.ntids[e]; i++) if (!std::binary_search(dead.begin(), dead.end(), g.tids[e][i])) g.tids[e][k++] = g.tids[e][i];
+            g.ntids[e] = k;
+        }
+        if (g.ntids[e] == 0) del[e] = 1;
+        else if (g.level[e] > highest_level && (int64_t)e != g.entry) { highest = e; highest_level = g.level[e]; }
+    }
+    auto needs_updated = [&](uint32_t e) {                                          // vacuum.rs:230-285
+        for (int lc = 0; lc <= g.level[e]; lc++) { const Cand *l = g.list(e, lc); for (uint16_t k = 0; k < g.cnt(e, lc); k++) if (del[l[k].id]) return true; }
+        return g.cnt(e, 0) < (uint16_t)g.lm(0);
+    };
+    uint64_t n_rep = 0;
+    auto &dts = ix->disk_pool;
+    // repairs `elems` (each against `entries[i]`) in lock-step, then overwrites their neighbour tuples (vacuum.rs:288-407)
+    auto repair = [&](const std::vector<uint32_t> &elems, const std::vector<int64_t> &entries) -> int {
+        std::vector<LsTask *> tasks; std::vector<uint32_t> who;
+        while (dts.size() < elems.size()) dts.emplace_back(new DiskNeighborsTask());
+        for (size_t i = 0; i < elems.size(); i++) {
+            if (entries[i] < 0 || (int64_t)elems[i] == entries[i]) continue;       // vacuum.rs:300-303
+            DiskNeighborsTask &t = *dts[tasks.size()];
+            t.reset();
+            t.g = &g; t.query_sel = elems[i]; t.new_level = g.level[elems[i]]; t.entry = (uint32_t)entries[i]; t.entry_level = g.level[entries[i]]; t.efc = ix->efc;
+            t.skip = del.data(); t.skip_self = elems[i]; t.repair = true;
+            tasks.push_back(&t); who.push_back(elems[i]);
+        }
+        int r = ix->run_lockstep(tasks);
+        if (r) return r;
+        for (size_t i = 0; i < who.size(); i++) {
+            DiskNeighborsTask &t = *static_cast<DiskNeighborsTask *>(tasks[i]);
+            const uint32_t e = who[i];
+            ix->counters[4] += t.n_dist;
+            for (int lc = 0; lc <= g.level[e]; lc++) {
+                Cand *lst = g.list(e, lc); const size_t c = lc < (int)t.nb.size() ? std::min(t.nb[lc].size(), (size_t)g.lm(lc)) : 0;
+                for (size_t k = 0; k < c; k++) lst[k] = t.nb[lc][k];
+                g.cnt(e, lc) = (uint16_t)c;
+            }
+            ix->mark_dirty(e);
+            n_rep++;
+        }
+        return HX_OK;
+    };
+    // pass 2: the entry point first (vacuum.rs:411-520)
+    if (highest >= 0 && !g.deleted[highest] && needs_updated((uint32_t)highest) && (rc = repair({(uint32_t)highest}, {g.entry}))) return rc;
+    if (g.entry >= 0) {
+        if (del[g.entry]) g.entry = highest;
+        else if (!g.deleted[g.entry] && needs_updated((uint32_t)g.entry) && (rc = repair({(uint32_t)g.entry}, {highest >= 0 ? highest : g.entry}))) return rc;
+    }
+    std::vector<uint32_t> grp; std::vector<int64_t> ent;
+    auto flush = [&]() -> int { if (grp.empty()) return HX_OK; int r = repair(grp, ent); grp.clear(); ent.clear(); return r; };
+    for (uint32_t e = 0; e < n; e++) {                                              // vacuum.rs:540-640
+        if (g.level[e] < 0 || g.ntids[e] == 0 || g.deleted[e]) continue;
+        if (!needs_updated(e)) continue;
+        if (g.entry < 0 || g.level[e] > g.level[g.entry]) {                         // may become the entry point: on its own, in order
+            if ((rc = flush())) return rc;
+            if ((rc = repair({e}, {g.entry}))) return rc;
+            if (g.entry < 0 || g.level[e] > g.level[g.entry]) g.entry = e;
+            continue;
+        }
+        grp.push_back(e); ent.push_back(g.entry);
+        if (grp.size() >= batch && (rc = flush())) return rc;
+    }
+    if ((rc = flush())) return rc;
+    uint64_t n_del = 0;
+    for (uint32_t e = 0; e < n; e++) {                                              // pass 3, vacuum.rs:655-793
+        if (g.level[e] < 0 || g.deleted[e] || g.ntids[e] > 0) continue;
+        for (int lc = 0; lc <= g.level[e]; lc++) g.cnt(e, lc) = 0;
+        g.deleted[e] = 1; ix->mark_dirty(e); n_del++;
+    }
+    if (n_deleted_out) *n_deleted_out = n_del;
+    if (n_repaired_out) *n_repaired_out = n_rep;
+    return HX_OK;
+}
+
+int hx_index_deleted(const hx_index *ix, uint32_t elem) { if (!ix || elem >= ix->g.size()) return HX_E_ARG; return ix->g.deleted[elem]; }
 
 uint32_t hx_index_size(const hx_index *ix) { return ix ? ix->g.size() : 0; }
 int64_t hx_index_entry(const hx_index *ix) { return ix ? ix->g.entry : -1; }

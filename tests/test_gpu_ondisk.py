@@ -1,0 +1,175 @@
+"""SURVEY 8f row f3 on the device: aminsert's neighbour search / get_update_index (src/index/insert.rs:500-739, 1021-1123) and vacuum's
+repair search (src/index/vacuum.rs:288-407) through hx_index_insert_ondisk / hx_index_vacuum, against the oracle's restatement --
+graphs (ids and distance bits), heap TIDs, entry point and deleted flags identical -- and the reference's gates 013 / 014."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pgvector_rx_amd as hx
+from oracle import orc
+from test_gpu_index import assert_same_graph, build_both, make_rows
+
+pytestmark = pytest.mark.gpu
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+METRIC = {"l2": hx.L2SQ, "ip": hx.NEG_IP, "cosine": hx.NEG_IP, "l1": hx.L1}
+
+CASES = [
+    (hx.F32, hx.L2SQ, 8, 900, 8, 32),
+    (hx.F32, hx.NEG_IP, 16, 600, 4, 16),
+    (hx.F16, hx.L1, 12, 500, 16, 64),
+    (hx.BIT, hx.HAMMING, 64, 700, 6, 24),       # ties everywhere: stable sorts and heap order decide
+    (hx.F32, hx.L2SQ, 3, 500, 20, 48),          # m = 20: lists of 40 (the pair blocks of get_update_index reach 40 rows)
+]
+
+
+@pytest.mark.parametrize("dtype,metric,dim,n,m,efc", CASES)
+def test_ondisk_insert_identical_to_oracle(dtype, metric, dim, n, m, efc):
+    """Every row through aminsert, one at a time (batch = 1 is the reference's schedule)."""
+    rng = np.random.default_rng(dim + n)
+    rows = make_rows(dtype, n, dim, rng)
+    rows[200] = rows[17]
+    rows[201] = rows[17]                     # duplicates: find_duplicate_on_disk / add_duplicate_on_disk
+    levels = hx.draw_levels(n, m, seed=9)
+    e = hx.Engine(dtype, metric, dim, n)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    elem = ix.insert_ondisk(0, levels, batch=1)
+    o = orc.Index(dtype, metric, dim, m=m, ef_construction=efc, order=orc.W64)
+    o.set_ondisk_tombstones(True)
+    oelem = np.array([o.insert_on_disk(rows[i], levels[i], i) for i in range(n)])
+    assert elem.tolist() == oelem.tolist()
+    if metric != hx.NEG_IP:                  # inner product: d(x, x) = -|x|^2 != 0, so the zero-distance duplicate test never fires (build.rs:486, insert.rs:1190)
+        assert elem[200] == 17 and elem[201] == 17
+    assert_same_graph(ix, o, n)
+    qs = make_rows(dtype, 12, dim, rng)
+    e.set_queries(qs)
+    tids, d, _, cnt = ix.search(12, 40, 10)                      # the device scan sees the lists the on-disk path wrote
+    for q in range(12):
+        assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=40, limit=10)]
+    ix.close()
+    e.close()
+
+
+def test_ondisk_insert_into_a_built_index():
+    """The usual life of an index: CREATE INDEX (batched device build), then INSERTs (aminsert) -- both halves equal the oracle's."""
+    rng = np.random.default_rng(5)
+    n0, n1, dim, m, efc = 2000, 300, 24, 16, 64
+    rows = make_rows(hx.F32, n0 + n1, dim, rng)
+    levels = hx.draw_levels(n0 + n1, m, seed=5)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n0 + n1)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    ix.insert(0, levels[:n0], batch=256)
+    ix.insert_ondisk(n0, levels[n0:], batch=1)
+    o = orc.Index(orc.F32, orc.L2SQ, dim, m=m, ef_construction=efc, order=orc.W64)
+    o.set_ondisk_tombstones(True)
+    i = 0
+    for b in hx.batch_schedule(0, n0, 256):
+        o.insert_batch(rows[i:i + b], levels[i:i + b], np.arange(i, i + b))
+        i += b
+    for i in range(n0, n0 + n1):
+        o.insert_on_disk(rows[i], levels[i], i)
+    assert_same_graph(ix, o, n0 + n1)
+    ix.close()
+    e.close()
+
+
+@pytest.mark.parametrize("dtype,metric,dim,m,efc", [(hx.F32, hx.L2SQ, 3, 4, 8), (hx.BIT, hx.HAMMING, 40, 8, 32)])
+def test_vacuum_identical_to_oracle(dtype, metric, dim, m, efc):
+    rng = np.random.default_rng(14 + dim)
+    n = 1500
+    rows = make_rows(dtype, n, dim, rng)
+    rows[700] = rows[3]                                           # an element with two heap TIDs: one dies, one stays
+    levels = hx.draw_levels(n, m, seed=14)
+    e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, 64)
+    dead = np.concatenate([np.arange(400, 1100), [3]]).astype(np.int64)      # tid 3 dies, tid 700 keeps element 3 alive
+    dead = dead[dead != 700]
+    nd, nr = ix.vacuum(dead, batch=1)
+    o.vacuum(dead)
+    assert nd == sum(o.deleted(i) for i in range(n)) and nr > 0
+    assert [ix.deleted(i) for i in range(n)] == [o.deleted(i) for i in range(n)]
+    assert ix.heaptids(3) == [700]
+    assert_same_graph(ix, o, n)
+    qs = make_rows(dtype, 16, dim, rng)
+    e.set_queries(qs)
+    tids, d, _, cnt = ix.search(16, 40, 10)
+    dead_set = set(dead.tolist())
+    for q in range(16):
+        want = [t for t, _, _ in o.scan(qs[q], ef_search=40, limit=10)]
+        assert tids[q, :cnt[q]].tolist() == want and not (set(want) & dead_set)
+    # inserts continue on the vacuumed index (slots of deleted elements are not reused here: rows are appended)
+    ix.close()
+    e.close()
+
+
+@pytest.mark.parametrize("gate", G["insert_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
+def test_insert_recall_gate_on_device(gate):
+    """tests/t/013_hnsw_vector_insert_recall.pl:104 at its full size: 10 000 rows inserted through aminsert, 10 at a time (the test's 10
+    concurrent pgbench clients), recall@20 >= 0.99 (0.97 inner product)."""
+    rng = np.random.default_rng(13)
+    n, dim, k = gate["rows"], gate["dim"], gate["k"]
+    raw = (rng.random((n, dim)) * rng.random((n, dim))).astype(np.float32)
+    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    levels = hx.draw_levels(n, gate["m"], seed=13)
+    r64, q64 = raw.astype(np.float64), qs.astype(np.float64)
+    for metric, min_recall in gate["min_recall"].items():
+        cosine = metric == "cosine"
+        e = hx.Engine(hx.F32, METRIC[metric], dim, n)
+        e.append(raw)
+        if cosine:
+            assert (e.normalize_rows(0, n) > 0).all()
+        ix = hx.Index(e, gate["m"], gate["ef_construction"])
+        ix.insert_ondisk(0, levels, batch=gate["clients"])
+        e.set_queries(qs, normalize=cosine)
+        tids, _, _, cnt = ix.search(len(qs), gate["ef_search"], k)
+        correct = 0
+        for q in range(len(qs)):
+            if metric == "l2":
+                dist = ((r64 - q64[q]) ** 2).sum(1)
+            elif metric == "ip":
+                dist = -(r64 @ q64[q])
+            elif metric == "l1":
+                dist = np.abs(r64 - q64[q]).sum(1)
+            else:
+                dist = 1.0 - (r64 @ q64[q]) / np.sqrt((r64 ** 2).sum(1) * (q64[q] ** 2).sum())
+            correct += len(set(np.argsort(dist, kind="stable")[:k].tolist()) & set(tids[q, :cnt[q]].tolist()))
+        assert correct / (k * len(qs)) >= min_recall, (metric, correct / (k * len(qs)))
+        ix.close()
+        e.close()
+
+
+@pytest.mark.parametrize("gate", G["vacuum_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
+def test_vacuum_recall_gate_on_device(gate):
+    """tests/t/014_hnsw_vector_vacuum_recall.pl:89-95 at its full size (10 000 rows, m = 4, ef_construction = 8, 7 500 rows deleted)."""
+    rng = np.random.default_rng(14)
+    n, dim, k, keep = gate["rows"], gate["dim"], gate["k"], gate["keep"]
+    rows = rng.random((n, dim)).astype(np.float32)
+    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    levels = hx.draw_levels(n, gate["m"], seed=14)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+    e.append(rows)
+    ix = hx.Index(e, gate["m"], gate["ef_construction"])
+    ix.insert(0, levels, tids=np.arange(1, n + 1), batch=64)
+    e.set_queries(qs)
+    d2 = ((qs[:, None, :].astype(np.float64) - rows[None, :keep, :].astype(np.float64)) ** 2).sum(2)
+    exact = (np.argsort(d2, axis=1, kind="stable")[:, :k] + 1).tolist()
+
+    def recall(ef_search, alive):
+        tids, _, _, cnt = ix.search(len(qs), ef_search, ef_search)            # the index hands over ef_search tuples; the heap visit drops the dead
+        c = 0
+        for q in range(len(qs)):
+            got = [t for t in tids[q, :cnt[q]].tolist() if alive(t)][:k]
+            c += len(set(got) & set(exact[q]))
+        return c / (k * len(qs))
+    for g in gate["before_vacuum"]:
+        assert recall(g["ef_search"], lambda t: t <= keep) >= g["min_recall"], ("before", g)
+    nd, nr = ix.vacuum(np.arange(keep + 1, n + 1), batch=64)
+    assert nd == n - keep and nr > 0
+    for g in gate["after_vacuum"]:
+        assert recall(g["ef_search"], lambda t: True) >= g["min_recall"], ("after", g)
+    tids, _, _, cnt = ix.search(len(qs), 100, 100)
+    assert all(t <= keep for q in range(len(qs)) for t in tids[q, :cnt[q]].tolist())
+    ix.close()
+    e.close()

@@ -370,3 +370,67 @@ def test_iterative_recall_gate(gate):
                     correct += sum(1 for t in got if t in ok)
                     total += limit
                 assert correct / total >= gate["min_recall"], (metric, c, mode, correct / total)
+
+
+def _live_recall(idx, qs, exact, ef_search, k, alive):
+    """What `SELECT ... ORDER BY v <-> q LIMIT k` returns when the index still holds dead TIDs: the scan's ef_search tuples in order,
+    the dead ones dropped by the heap visit, the first k kept."""
+    correct = 0
+    for i, q in enumerate(qs):
+        got = [t for t, _, _ in idx.scan(q, ef_search=ef_search) if alive(t)][:k]
+        correct += len(set(got) & set(exact[i]))
+    return correct / (k * len(qs))
+
+
+@pytest.mark.parametrize("gate", G["insert_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
+def test_insert_recall_gate(gate):
+    """tests/t/013: an index filled ONLY through aminsert (find_element_neighbors_on_disk + get_update_index) reaches the build path's recall."""
+    rng = np.random.default_rng(13)
+    n, dim, k = 3000, gate["dim"], gate["k"]                  # the gate is size-free; 3000 rows keep the CPU suite short
+    raw = (rng.random((n, dim)) * rng.random((n, dim))).astype(np.float32)
+    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    levels = orc.levels_from_seed(n, gate["m"], 13)
+    for metric, min_recall in gate["min_recall"].items():
+        idx = orc.Index(orc.F32, METRIC[metric], dim, m=gate["m"], ef_construction=gate["ef_construction"])
+        for i in range(n):
+            r = raw[i]
+            if metric == "cosine":
+                r, norm = orc.l2_normalize(orc.F32, dim, r)
+                if norm == 0.0:
+                    continue
+            idx.insert_on_disk(r, levels[i], i)
+        correct = 0
+        for q in qs:
+            _, exact = _exact_topk("vector", metric, raw, q, k)
+            qq = orc.l2_normalize(orc.F32, dim, q)[0] if metric == "cosine" else q
+            got = [t for t, _, _ in idx.scan(qq, ef_search=gate["ef_search"], limit=k)]
+            correct += len(set(exact.tolist()) & set(got))
+        assert correct / (k * len(qs)) >= min_recall, (metric, correct / (k * len(qs)))
+
+
+@pytest.mark.parametrize("gate", G["vacuum_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
+def test_vacuum_recall_gate(gate):
+    """tests/t/014 at its full size: 10 000 rows, m = 4, ef_construction = 8; rows 2501.. deleted; recall before and after VACUUM."""
+    rng = np.random.default_rng(14)
+    n, dim, k, keep = gate["rows"], gate["dim"], gate["k"], gate["keep"]
+    rows = rng.random((n, dim)).astype(np.float32)
+    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    levels = orc.levels_from_seed(n, gate["m"], 14)
+    idx = orc.Index(orc.F32, orc.L2SQ, dim, m=gate["m"], ef_construction=gate["ef_construction"])
+    idx.build(rows, levels, batch=1, tids=np.arange(1, n + 1))
+    d2 = ((qs[:, None, :].astype(np.float64) - rows[None, :keep, :].astype(np.float64)) ** 2).sum(2)
+    exact = (np.argsort(d2, axis=1, kind="stable")[:, :k] + 1).tolist()
+    for g in gate["before_vacuum"]:
+        r = _live_recall(idx, qs, exact, g["ef_search"], k, lambda t: t <= keep)
+        assert r >= g["min_recall"], ("before", g, r)
+    idx.vacuum(np.arange(keep + 1, n + 1))
+    assert sum(idx.deleted(e) for e in range(n)) == n - keep
+    for g in gate["after_vacuum"]:
+        r = _live_recall(idx, qs, exact, g["ef_search"], k, lambda t: True)
+        assert r >= g["min_recall"], ("after", g, r)
+    # nothing dead is returned any more, and no live element links to a deleted one
+    assert all(t <= keep for q in qs for t, _, _ in idx.scan(q, ef_search=100))
+    for e in range(n):
+        if not idx.deleted(e):
+            for layer in range(idx.level(e) + 1):
+                assert all(not idx.deleted(int(x)) for x in idx.neighbors(e, layer)[0])

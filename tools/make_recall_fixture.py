@@ -17,8 +17,8 @@ sys.path.insert(0, ROOT)
 from oracle import orc  # noqa: E402
 import pgvector_rx_amd as hx  # noqa: E402
 
-CFG = {"rows": 100_000, "dim": 768, "m": 16, "ef_construction": 200, "ef_search": [40, 100], "k": 10, "queries": 1000,
-       "centres": 1024, "sigma": 0.1, "seed_rows": 2026, "seed_queries": 2027, "seed_levels": 2026}
+CFG = {"rows": 100_000, "dim": 768, "m": 16, "ef_construction": 200, "ef_search": [10, 20, 40, 100], "k": 10, "queries": 1000,
+       "centres": 96, "sigma": 0.1, "seed_rows": 2026, "seed_queries": 2027, "seed_levels": 2026}
 
 
 def make_data(cfg):
