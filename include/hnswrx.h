@@ -304,6 +304,14 @@ int hx_index_serialize_pages(const hx_index *ix, uint8_t *pages_out, uint64_t ca
 int hx_index_load_pages(hx_index *ix, const uint8_t *pages, uint64_t n_pages, uint32_t *elem_blkno_out, uint16_t *elem_offno_out,
                         uint64_t cap_elems, uint64_t *n_elems_out);
 
+/* Version-checked invalidation of a loaded index.  The scan side trusts a neighbour tuple only while its version equals
+ * the element's (load_neighbor_tids, scan.rs:262-265; HnswElementTupleData.version, types/hnsw.rs:120 -- vacuum bumps it when it frees a
+ * tuple, so a reused slot no longer matches).  A host that changes pages under a loaded mirror reports the element tuples it touched with
+ * their CURRENT versions: every (blkno[i], offno[i]) whose version differs from the one that was loaded (versions == NULL: every listed
+ * tuple) is dropped from the mirror -- no heap TIDs, no lists, unlinked from all neighbour lists, entry point re-picked -- so device scans
+ * neither return nor traverse a tuple whose slot now holds something else.  *n_dropped_out = elements dropped. */
+int hx_index_invalidate(hx_index *ix, uint32_t n, const uint32_t *blkno, const uint16_t *offno, const uint8_t *versions, uint32_t *n_dropped_out);
+
 #ifdef __cplusplus
 }
 #endif

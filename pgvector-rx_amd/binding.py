@@ -76,6 +76,7 @@ def lib():
         "hx_index_insert_ondisk": (i32, [vp, u64, u32, vp, vp, u32, vp]),
         "hx_index_vacuum": (i32, [vp, vp, u64, u32, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_deleted": (i32, [vp, u32]),
+        "hx_index_invalidate": (i32, [vp, u32, vp, vp, vp, C.POINTER(u32)]),
         "hx_index_dbatch_supported": (i32, [vp, vp, u32]),
         "hx_index_dbatch_record_bytes": (u64, [vp]),
         "hx_index_dbatch_list_record_bytes": (u64, [vp]),
@@ -298,6 +299,15 @@ class Index:
 
     def deleted(self, e):
         return lib().hx_index_deleted(self.h, e)
+
+    def invalidate(self, blkno, offno, versions=None):
+        """Drops loaded elements whose tuple version changed (scan.rs:262-265); returns how many were dropped."""
+        b = np.ascontiguousarray(blkno, np.uint32)
+        o = np.ascontiguousarray(offno, np.uint16)
+        v = None if versions is None else np.ascontiguousarray(versions, np.uint8)
+        nd = C.c_uint32(0)
+        self._ck(lib().hx_index_invalidate(self.h, len(b), _p(b), _p(o), _p(v), C.byref(nd)))
+        return nd.value
 
     # ---- staged batch (multi-GPU build; see dist_build.py) ----
     def batch_begin(self, first_row, levels, tids):

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <thread>
 #include <chrono>
+#include <unordered_map>
 
 namespace {
 
@@ -703,6 +704,8 @@ struct hx_index {
     std::vector<std::unique_ptr<DiskNeighborsTask>> disk_pool;
     std::vector<std::unique_ptr<UpdateIndexTask>> update_pool;
     bool fused = true;                                         // device-resident traversal (hx_fused.inc.h) for searches
+    // index loaded from its page image (hx_index_load_pages): where each element tuple sits and the version it carried (types/hnsw.rs:120)
+    std::vector<uint32_t> loc_blk; std::vector<uint16_t> loc_off; std::vector<uint8_t> loc_ver; std::unordered_map<uint64_t, uint32_t> loc2elem;
     std::vector<std::pair<uint32_t, int>> dirty;               // (element, layer) lists the device mirror has not seen yet
     uint32_t mirror_elems = 0;
     uint64_t fused_tasks = 0, fused_redo = 0;
@@ -1777,6 +1780,54 @@ int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uin
     return HX_OK;
 }
 
+
+// f2: version-checked invalidation of an index loaded from its page image.  The scan side trusts a neighbour tuple only while its version
+// equals the element's (load_neighbor_tids, scan.rs:262-265; HnswElementTupleData.version, types/hnsw.rs:120: vacuum bumps it when it frees
+// a tuple, so a reused slot no longer matches).  When the host changes pages under a loaded mirror it reports the tuples it touched:
+// every listed (blkno, offno) whose CURRENT version differs from the one loaded (versions == NULL: unconditionally) is dropped from the
+// mirror -- no heap TIDs, no lists, unlinked from every neighbour list (order of the survivors kept), entry point re-picked like
+// vacuum does (highest remaining level) -- so that device scans never return or traverse a tuple whose slot now holds something else.
+int hx_index_invalidate(hx_index *ix, uint32_t n, const uint32_t *blkno, const uint16_t *offno, const uint8_t *versions, uint32_t *n_dropped_out)
+{
+    if (!ix || (n && (!blkno || !offno))) return HX_E_ARG;
+    if (n_dropped_out) *n_dropped_out = 0;
+    Graph &g = ix->g;
+    if (ix->loc2elem.empty()) return ix->fail(HX_E_STATE, "the index was not loaded from pages (hx_index_load_pages)");
+    int rc = ix->ensure_host_lists();
+    if (rc) return rc;
+    std::vector<uint8_t> drop(g.size(), 0); uint32_t nd = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        auto it = ix->loc2elem.find(((uint64_t)blkno[i] << 16) | offno[i]);
+        if (it == ix->loc2elem.end()) continue;                                   // a tuple the mirror never held
+        const uint32_t e = it->second;
+        if (g.deleted[e] || drop[e]) continue;
+        if (versions && versions[i] == ix->loc_ver[e]) continue;                  // still the tuple that was loaded
+        drop[e] = 1; nd++;
+    }
+    if (n_dropped_out) *n_dropped_out = nd;
+    if (!nd) return HX_OK;
+    const uint32_t N = g.size();
+    for (uint32_t e = 0; e < N; e++) {
+        if (g.level[e] < 0) continue;
+        if (drop[e]) {
+            for (int lc = 0; lc <= g.level[e]; lc++) g.cnt(e, lc) = 0;
+            g.ntids[e] = 0; g.deleted[e] = 1; ix->mark_dirty(e);
+            continue;
+        }
+        for (int lc = 0; lc <= g.level[e]; lc++) {
+            Cand *l = g.list(e, lc); uint16_t &c = g.cnt(e, lc); uint16_t w = 0;
+            for (uint16_t k = 0; k < c; k++) if (!drop[l[k].id]) l[w++] = l[k];
+            if (w != c) { c = w; ix->dirty.emplace_back(e, lc); }
+        }
+    }
+    if (g.entry >= 0 && drop[g.entry]) {
+        int64_t best = -1;
+        for (uint32_t e = 0; e < N; e++) if (g.level[e] >= 0 && !g.deleted[e] && g.ntids[e] > 0 && (best < 0 || g.level[e] > g.level[best])) best = e;
+        g.entry = best;
+    }
+    return HX_OK;
+}
+
 int hx_index_deleted(const hx_index *ix, uint32_t elem) { if (!ix || elem >= ix->g.size()) return HX_E_ARG; return ix->g.deleted[elem]; }
 
 uint32_t hx_index_size(const hx_index *ix) { return ix ? ix->g.size() : 0; }
@@ -2260,6 +2311,8 @@ int hx_index_load_pages(hx_index *ix, const uint8_t *pages, uint64_t n_pages, ui
         const uint8_t *t = pages + (size_t)els[i].blk * PG_BLCKSZ + els[i].lo;
         const int level = t[1];
         g.add(level);
+        ix->loc_blk.push_back(els[i].blk); ix->loc_off.push_back((uint16_t)els[i].off); ix->loc_ver.push_back(t[3]);
+        ix->loc2elem[((uint64_t)els[i].blk << 16) | els[i].off] = i;
         uint8_t nt = 0;
         for (uint32_t k = 0; k < HEAPTIDS; k++) {
             const TidRef h = get_tid(t + 4 + k * TID_BYTES);

@@ -266,3 +266,48 @@ def test_load_pages_rejects_malformed_images():
     ix.load_pages(pages)
     with pytest.raises(hx.HxError):
         ix.load_pages(pages)                                                 # not empty any more
+
+
+@pytest.mark.gpu
+def test_invalidate_drops_elements_whose_tuple_version_changed():
+    """f2: a host that rewrites element tuples under a loaded mirror reports (blkno, offno, current version); tuples whose version no
+    longer matches the loaded one (scan.rs:262-265, types/hnsw.rs:120) leave the mirror: never returned, never traversed, and the scan
+    over the rest equals an exact scan restricted to the survivors to the usual recall."""
+    import pgvector_rx_amd as hx
+    dim, n, m, efc = 8, 1200, 8, 32
+    rows, levels = make_rows(orc.F32, dim, n, m, 33)
+    e1 = hx.Engine(orc.F32, orc.L2SQ, dim, n); e1.append(rows)
+    a = hx.Index(e1, m, efc); a.insert(0, levels, heap_tids(n), batch=32)
+    pages, blk, off = a.serialize_pages()
+    e2 = hx.Engine(orc.F32, orc.L2SQ, dim, n)
+    b = hx.Index(e2, m, efc)
+    lblk, loff = b.load_pages(pages)
+    # same versions (0, as built): nothing happens; unknown locations are ignored
+    assert b.invalidate(lblk[:50], loff[:50], np.zeros(50, np.uint8)) == 0
+    assert b.invalidate([999999], [1], [3]) == 0
+    victims = np.unique(np.concatenate([[int(b.entry)], np.arange(5, n, 17)]))          # the entry point among them
+    assert b.invalidate(lblk[victims], loff[victims], np.full(len(victims), 1, np.uint8)) == len(victims)
+    assert b.invalidate(lblk[victims], loff[victims], np.full(len(victims), 1, np.uint8)) == 0     # already dropped
+    vset = set(victims.tolist())
+    assert b.entry >= 0 and int(b.entry) not in vset
+    for i in range(n):
+        if i in vset:
+            assert b.deleted(i) == 1 and b.heaptids(i) == []
+        for layer in range(max(b.level(i), 0) + 1):
+            ids, _ = b.neighbors(i, layer)
+            assert not (set(ids.tolist()) & vset) and (i not in vset or len(ids) == 0)
+    rng = np.random.default_rng(3)
+    qs = rng.random((40, dim), dtype=np.float32)
+    e2.set_queries(qs)
+    tids, d, el, cnt = b.search(40, 64, 10)
+    alive = np.array([i for i in range(n) if i not in vset])
+    d2 = ((qs[:, None, :].astype(np.float64) - rows[alive][None, :, :].astype(np.float64)) ** 2).sum(2)
+    hit = 0
+    for q in range(40):
+        got = el[q, :cnt[q]].tolist()
+        assert not (set(got) & vset)
+        hit += len(set(got) & set(alive[np.argsort(d2[q])[:10]].tolist()))
+    assert hit / 400 >= 0.9
+    # an index that was built, not loaded, has nothing to invalidate against
+    with pytest.raises(hx.HxError):
+        a.invalidate([1], [1], [0])
