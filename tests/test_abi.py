@@ -66,3 +66,16 @@ def test_levels_match_reference_formula():
     a = hx.draw_levels(100, 16, 9, start=50)
     b = hx.draw_levels(150, 16, 9)[50:]
     assert (a == b).all()
+
+
+def test_rust_and_python_bindings_cover_the_header():
+    """The reference-side binding a maintainer would add (integration/rust/src/gpu/ffi.rs, an `extern "C"` block) and the ctypes binding
+    declare exactly the entry points of include/hnswrx.h: nothing missing, nothing the header does not have."""
+    names = set(declared_symbols())
+    rs = open(os.path.join(ROOT, "integration", "rust", "src", "gpu", "ffi.rs")).read()
+    block = rs[rs.index('extern "C" {'):]
+    rust = set(re.findall(r"pub fn (hx_[a-z0-9_]+)\s*\(", block[:block.index("\n}\n")]))
+    assert rust == names, (sorted(names - rust), sorted(rust - names))
+    py = open(os.path.join(ROOT, "pgvector-rx_amd", "binding.py")).read()
+    bound = set(re.findall(r'"(hx_[a-z0-9_]+)":\s*\(', py))
+    assert bound == names, (sorted(names - bound), sorted(bound - names))

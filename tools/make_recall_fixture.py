@@ -63,7 +63,8 @@ def main():
     for efs in cfg["ef_search"]:
         ids, cnt = o.search_many(qs, efs, cfg["k"], n_threads=8)
         per_q = np.array([len(set(ids[q, :cnt[q]].tolist()) & set(gt[q].tolist())) / cfg["k"] for q in range(len(qs))])
-        out["recall_at_k"][str(efs)] = {"mean": float(per_q.mean()), "std_of_mean": float(per_q.std(ddof=1) / np.sqrt(len(per_q)))}
+        out["recall_at_k"][str(efs)] = {"mean": float(per_q.mean()), "std_of_mean": float(per_q.std(ddof=1) / np.sqrt(len(per_q))),
+                                        "hits_per_query": "".join("%x" % int(round(v * cfg["k"])) for v in per_q)}   # one hex digit per query (k = 10): lets the device test compare query by query
         print("ef_search %d: recall@%d %.4f" % (efs, cfg["k"], per_q.mean()), flush=True)
     out["distance_evaluations"] = {"search": o.counters()[1], "select": o.counters()[2], "backlink": o.counters()[3]}
     path = os.path.join(ROOT, "tests", "golden", "recall_parity_100k.json")
