@@ -157,12 +157,22 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
     clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
     if (dev && dev->d_wtab) clds = std::max<uint32_t>(clds, dev->wt_size);                     // so does the W table
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 16 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
     { const char *pv = getenv(mode == 0 ? "HX_QUERY_PER_CU" : "HX_INSERT_PER_CU"); if (mode != 2 && pv && atoi(pv) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(pv)); }   // tuning knob
     uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
+    // k_fused2 (rows wider than 512 B, queries and inserts): one 1024-thread workgroup per CU, nc control waves + (16 - nc) stream waves
+    static const int fused2_env = getenv("HX_FUSED2") ? atoi(getenv("HX_FUSED2")) : 0;   // experimental pooled-stream kernel: opt-in (measured slower than one wave per search so far)
+    const uint32_t slot_bytes = (uint32_t)((lds + 15) & ~(size_t)15);
+    uint32_t nc2 = 0;
+    if (fused2_env && mode != 2 && pitch > 512 && ntasks >= 64) {
+        nc2 = (uint32_t)std::min<size_t>(15, (160 * 1024 - 256) / slot_bytes);
+        { const char *cv = getenv("HX_FUSED2_NC"); if (cv && atoi(cv) > 0) nc2 = std::min<uint32_t>(nc2, (uint32_t)atoi(cv)); }   // tuning knob
+        if (nc2 < 4) nc2 = 0;                                      // very wide rows with a large ef: too few searches per workgroup to feed stream waves
+        else grid = std::min<uint32_t>((ntasks + nc2 - 1) / nc2, 256u);
+    }
     // >= 2x the ids a search touches at its usual ~ef expansions; twice that on indexes of >= 4M rows, where some searches reach further.
     // Measured on 1M x 768: a table twice as large costs 3-6 % of the scan rate (cache footprint), one half as large overflows and retries.
     const uint64_t vis_need = ((uint64_t)ef * 2 * mr.m * 2 + 1024) * (n_rows >= 4000000ull ? 2 : 1);
@@ -268,8 +278,10 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     }
     if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
     hipError_t ls = hipSuccess;
-    ls = dtype == HX_F32 ? hx_launch_fused_f32(this, metric, p, grid, lds, mode)
-       : dtype == HX_F16 ? hx_launch_fused_f16(this, metric, p, grid, lds, mode) : hx_launch_fused_bit(this, metric, p, grid, lds, mode);
+    if (nc2) ls = dtype == HX_F32 ? hx_launch_fused2_f32(this, metric, p, grid, nc2, slot_bytes, mode)
+               : dtype == HX_F16 ? hx_launch_fused2_f16(this, metric, p, grid, nc2, slot_bytes, mode) : hx_launch_fused2_bit(this, metric, p, grid, nc2, slot_bytes, mode);
+    else ls = dtype == HX_F32 ? hx_launch_fused_f32(this, metric, p, grid, lds, mode)
+            : dtype == HX_F16 ? hx_launch_fused_f16(this, metric, p, grid, lds, mode) : hx_launch_fused_bit(this, metric, p, grid, lds, mode);
     HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
     HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));

@@ -50,6 +50,9 @@ struct FusedParams {
 hipError_t hx_launch_fused_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_f16(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
+hipError_t hx_launch_fused2_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
+hipError_t hx_launch_fused2_f16(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
+hipError_t hx_launch_fused2_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
 
 struct FHeapItem { float d; uint32_t id; };
 __device__ __forceinline__ uint2 fh_pack(float d, uint32_t id) { return make_uint2(__builtin_bit_cast(unsigned int, d), id); }
@@ -119,6 +122,9 @@ template <bool NEAREST> struct FHeap {
 //     same path is again one ballot, and all the moves are one store.
 // The resulting array is the one the serial algorithm leaves, element for element (ties included).
 #define F_WSYNC() asm volatile("" ::: "memory")     /* LDS ops of one wave execute in order; only the compiler must not reorder */
+/* A search is driven by ONE wavefront, also when its workgroup has others (k_fused2): what the traversal code needs between its steps is
+   ordering inside that wave -- its earlier LDS and memory operations issued before its later ones -- never a workgroup barrier. */
+#define F_BAR() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
 // heap storage for PHeap: plain LDS, or an LDS head + a tail in this workgroup's global area (the `discarded` heap of an
 // iterative scan holds every visited element that is not a result: tens of thousands of entries).  The global part is read
 // and written with L1-bypassing 64-bit accesses because different lanes of the wave read what other lanes wrote.
@@ -256,6 +262,9 @@ struct FusedCtx {
     uint32_t *vis; uint32_t lane; uint32_t status;
     GStore DS; lds_uint2 *DP, *WS; uint32_t *LV; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
+    // k_fused2: row batches are posted to the workgroup's streaming waves
+    volatile uint32_t *SQ; float *DOUT; uint8_t *lds_base; uint32_t gen;
+    uint32_t slot_bytes, sq_off, dout_off, nc, my_slot;
     uint32_t tph[14];  // [13] select phase; diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
 };
 
@@ -268,7 +277,7 @@ __device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src,
         if (off < p.pitch) v = *(const u4 *)(src + off);
         *(u4 *)(dst + off) = v;
     }
-    __syncthreads();
+    F_BAR();
 }
 
 // f_park for code that runs in ONE wave of a multi-wave workgroup (no workgroup barrier)
@@ -347,32 +356,54 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
     unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
 #define FD_TICK(k) do { if (tk) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tk[k] += (uint32_t)(t_ - tq); tq = t_; } } while (0)
     const uint32_t loff = lane * 16u;
+    const bool ragged = (p.pitch & 1023u) != 0u;              // the last chunk of a row is partial: lanes past the payload must contribute zeros
     for (uint32_t j0 = 0; j0 < n; j0 += RB) {
-        const uint8_t *rp[RB];
+        // Row bases are wave-uniform (an id is one value for the whole wave): kept in scalar registers, so a load is base + per-lane offset and
+        // costs no address VGPRs.  Every load of a round is issued unconditionally, back to back, into its own registers: a lane past the payload
+        // re-reads the row's first bytes and its fragment is zeroed afterwards (a conditional load per fragment made the compiler serialise the
+        // round -- measured as two extra memory latencies per row batch).
+        const uint8_t *rb[RB];
 #pragma unroll
-        for (int r = 0; r < RB; r++) rp[r] = p.rows + (size_t)ids[j0 + r < n ? j0 + r : j0] * p.pitch + loff;
+        for (int r = 0; r < RB; r++) {
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)ids[j0 + r < n ? j0 + r : j0]);
+            rb[r] = p.rows + (size_t)id * p.pitch;
+        }
         typename OP::acc_t acc[RB];
 #pragma unroll
         for (int r = 0; r < RB; r++) OP::init(acc[r]);
 #pragma unroll 1
         for (uint32_t c0 = 0; c0 < p.nch; c0 += FUSED_CG) {
+            const uint32_t kc = p.nch - c0 < (uint32_t)FUSED_CG ? p.nch - c0 : (uint32_t)FUSED_CG;   // chunks of this round (uniform)
             u4 rv[RB][FUSED_CG];
+            uint32_t offk[FUSED_CG]; bool ink[FUSED_CG];
 #pragma unroll
-            for (int k = 0; k < FUSED_CG; k++) {
-                const uint32_t off = (c0 + k) * 1024u;
-                const bool in = c0 + k < p.nch && off + loff < p.pitch;
+            for (int k = 0; k < FUSED_CG; k++) { const uint32_t o = (c0 + (uint32_t)k) * 1024u + loff; ink[k] = o < p.pitch; offk[k] = ink[k] ? o : 0u; }
+            if (kc == (uint32_t)FUSED_CG) {
 #pragma unroll
-                for (int r = 0; r < RB; r++) { u4 v = {0u, 0u, 0u, 0u}; if (in) v = *(const u4 *)(rp[r] + off); rv[r][k] = v; }
+                for (int k = 0; k < FUSED_CG; k++)
+#pragma unroll
+                    for (int r = 0; r < RB; r++) rv[r][k] = *(const u4 *)(rb[r] + offk[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < FUSED_CG - 1; k++)
+                    if ((uint32_t)k < kc) {
+#pragma unroll
+                        for (int r = 0; r < RB; r++) rv[r][k] = *(const u4 *)(rb[r] + offk[k]);
+                    }
             }
             FD_TICK(9);                                   // addresses + load issue
             if (tk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FD_TICK(10);                                  // waiting for the rows
 #pragma unroll
             for (int k = 0; k < FUSED_CG; k++) {
-                if (c0 + k < p.nch) {
-                    const u4 q = *(const u4 *)(qv + (c0 + k) * 1024u + loff);
+                if ((uint32_t)k < kc) {
+                    const u4 q = *(const u4 *)(qv + (c0 + (uint32_t)k) * 1024u + loff);
 #pragma unroll
-                    for (int r = 0; r < RB; r++) OP::add(acc[r], q, rv[r][k]);
+                    for (int r = 0; r < RB; r++) {
+                        u4 v = rv[r][k];
+                        if (ragged && !ink[k]) v = u4{0u, 0u, 0u, 0u};
+                        OP::add(acc[r], q, v);
+                    }
                 }
             }
             if (tk) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -404,4 +435,114 @@ __device__ __forceinline__ bool f_any_le(const FusedParams &p, const uint8_t *qv
         if (__ballot(lane < nb && d <= thr) != 0ull) return true;
     }
     return false;
+}
+
+
+// =================================================================================================
+// Pooled row streaming (k_fused2).  One wave per search keeps the registers that hold rows in flight idle while it pops, looks
+// lists and visited buckets up and replays its heaps -- half of its time on the 1M x 768 workload -- and the register file is full
+// at 16 such waves per CU, so the idle share cannot be bought back with more waves.  In k_fused2 a workgroup has NC CONTROL waves
+// (one search each: heaps, lists, visited set, select -- no row ever enters their registers) and NS STREAM waves that do nothing
+// but evaluate row batches for whichever search has one posted: a control wave publishes {query parked in LDS, ids in LDS, n} in
+// its StreamQ, the stream waves carve the request into batches of FUSED_SRB rows with an LDS compare-and-swap, write the distances
+// to the search's LDS and count them done.  Same rows, same canonical summation order, same bits; only who loads them changed.
+// =================================================================================================
+#ifndef FUSED_SRB
+#define FUSED_SRB 8            /* rows in flight per stream wave (x FUSED_CG chunks: 96 VGPRs of row data) */
+#endif
+enum { SQ_REQ = 0, SQ_NEXT = 1, SQ_DONE = 2, SQ_QOFF = 3, SQ_IOFF = 4, SQ_WORDS = 8 };   // req / next: generation << 8 | count
+
+// takes one batch of the request posted in slot s, if any is left, and evaluates it; false: nothing to take there
+template <class OP>
+__device__ __forceinline__ bool f_stream_serve(const FusedParams &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t s, uint32_t lane)
+{
+    volatile uint32_t *q = (volatile uint32_t *)(lds + (size_t)s * slot_bytes + sq_off);
+    const uint32_t req = __hip_atomic_load((const uint32_t *)&q[SQ_REQ], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t n = req & 0xFFu;
+    if (n == 0u) return false;
+    uint32_t got = 0xFFFFFFFFu;
+    if (lane == 0) {
+        const uint32_t v = q[SQ_NEXT];
+        if ((v >> 8) == (req >> 8) && (v & 0xFFu) < n) {
+            uint32_t expect = v;
+            if (__hip_atomic_compare_exchange_strong((uint32_t *)&q[SQ_NEXT], &expect, v + (uint32_t)FUSED_SRB, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) got = v & 0xFFu;
+        }
+    }
+    got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+    if (got == 0xFFFFFFFFu) return false;
+    const uint32_t cnt = n - got < (uint32_t)FUSED_SRB ? n - got : (uint32_t)FUSED_SRB;
+    const uint8_t *qv = lds + q[SQ_QOFF];
+    const uint32_t *ids = (const uint32_t *)(lds + q[SQ_IOFF]) + got;
+    volatile float *dout = (volatile float *)(lds + (size_t)s * slot_bytes + dout_off) + got;
+    const float mine = f_dist_batch<OP, 64, FUSED_SRB>(p, qv, ids, cnt, lane);
+    if (lane < cnt) dout[lane] = mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) (void)__hip_atomic_fetch_add((uint32_t *)&q[SQ_DONE], cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
+}
+
+// Posts the rows ids[0..n) against the vector parked at qv and returns lane j's distance.  While the request is open the posting wave is
+// a stream wave itself: it takes batches of its own request first, then of its neighbours' -- a wave never idles next to unserved rows.
+template <class OP, int LPR>
+__device__ __forceinline__ float f_dist_posted(const FusedParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
+{
+    volatile uint32_t *q = cx.SQ;
+    F_BAR();                                                        // the ids (written by any lane) are in LDS before the request is
+    cx.gen = (cx.gen + 1u) & 0xFFFFFFu;
+    if (lane == 0) {
+        q[SQ_DONE] = 0u; q[SQ_QOFF] = (uint32_t)(qv - cx.lds_base); q[SQ_IOFF] = (uint32_t)((const uint8_t *)ids - cx.lds_base);
+        q[SQ_NEXT] = cx.gen << 8;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        q[SQ_REQ] = (cx.gen << 8) | n;
+    }
+    F_BAR();
+    uint32_t probe = cx.my_slot;
+    while (__hip_atomic_load((const uint32_t *)&q[SQ_DONE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n) {
+        if (f_stream_serve<OP>(p, cx.lds_base, cx.slot_bytes, cx.sq_off, cx.dout_off, probe, lane)) { probe = cx.my_slot; continue; }
+        probe = probe + 1u < cx.nc ? probe + 1u : 0u;
+        if (probe == cx.my_slot) __builtin_amdgcn_s_sleep(1);       // a full round without work: the rest of my rows is in other waves' registers
+    }
+    const float mine = lane < n ? ((volatile float *)cx.DOUT)[lane] : 0.0f;
+    if (lane == 0) q[SQ_REQ] = 0u;                                  // retired: nothing left to hand out
+    F_BAR();
+    return mine;
+}
+
+// query-vs-rows distances of one expansion / one check_element_closer step: by this wave itself, or posted to the stream waves
+template <class OP, int LPR, bool POSTED, int RB = FUSED_RB>
+__device__ __forceinline__ float f_dist(const FusedParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
+{
+    if constexpr (POSTED) return f_dist_posted<OP, LPR>(p, cx, qv, ids, n, lane);
+    else return f_dist_batch<OP, LPR, RB>(p, qv, ids, n, lane, tk);
+}
+
+template <class OP, int LPR, bool POSTED>
+__device__ __forceinline__ bool f_any_le_x(const FusedParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
+                                           unsigned long long &n_eval)
+{
+    constexpr uint32_t B = f_step_rows<LPR>();
+    for (uint32_t j0 = 0; j0 < n; j0 += B) {
+        const uint32_t nb = n - j0 < B ? n - j0 : B;
+        const float d = f_dist<OP, LPR, POSTED>(p, cx, qv, ids + j0, nb, lane);
+        n_eval += nb;
+        if (__ballot(lane < nb && d <= thr) != 0ull) return true;
+    }
+    return false;
+}
+
+// a stream wave: serves the nc searches of its workgroup until every control wave has quit
+template <class OP>
+__device__ void f_stream_loop(const FusedParams &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t nc,
+                              volatile uint32_t *quit, uint32_t lane, uint32_t sw)
+{
+    uint32_t s = sw % nc, idle = 0;
+    for (;;) {
+        if (f_stream_serve<OP>(p, lds, slot_bytes, sq_off, dout_off, s, lane)) { idle = 0; continue; }   // stay on a slot while it has batches
+        s = s + 1u < nc ? s + 1u : 0u;
+        if (++idle >= nc) {
+            idle = 0;
+            if (__hip_atomic_load((const uint32_t *)quit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= nc) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
 }

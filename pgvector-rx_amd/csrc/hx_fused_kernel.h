@@ -9,7 +9,7 @@
 // ITER: search_layer_disk WITH the iterative scan's state (scan.rs:302-448): the visited set is the caller's and survives
 // resumes (fresh == false keeps it; eps_visited == false: resume_scan_items' entry points are already in it), and every
 // visited element that does not end in W goes to the `discarded` min-heap, in the reference's order of pushes.
-template <class OP, int LPR, bool ITER = false>
+template <class OP, int LPR, bool ITER = false, bool POSTED = false>
 __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
 {
     const uint32_t lane = cx.lane;
@@ -114,14 +114,14 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     lds_uint2 *const CA = cx.CH.lds, *const WA = cx.WH.lds;
     auto c_push = [&](uint2 it) {
         if (clen < cx.CH.L) PHeap<true>::push(CA, clen, it, lane);
-        else { __syncthreads(); if (lane == 0) { uint32_t l = clen; FHeap<true>::push(cx.CH, l, it); } clen++; __syncthreads(); }
+        else { F_BAR(); if (lane == 0) { uint32_t l = clen; FHeap<true>::push(cx.CH, l, it); } clen++; F_BAR(); }
     };
     auto c_pop = [&]() -> uint2 {
         if (clen <= cx.CH.L) return PHeap<true>::pop(CA, clen, lane);
-        __syncthreads();
+        F_BAR();
         if (lane == 0) { uint32_t l = clen; const uint2 c = FHeap<true>::pop(cx.CH, l); cx.RES[0] = c; }
-        clen--; __syncthreads();
-        const uint2 c = cx.RES[0]; __syncthreads();
+        clen--; F_BAR();
+        const uint2 c = cx.RES[0]; F_BAR();
         return c;
     };
     for (uint32_t i = 0; i < n_ep; i++) {
@@ -130,7 +130,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         c_push(it); PHeap<false>::push(WA, wl, it, lane);
     }
     rlen = wl;
-    __syncthreads();
+    F_BAR();
     for (;;) {
         if (cx.status != FS_OK) break;
         // pop the nearest candidate, decide whether to stop
@@ -180,9 +180,9 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             if (vcount * 4u > (uint32_t)p.vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
             if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
-            __syncthreads();
+            F_BAR();
             F_TICK(3);
-            const float mine = f_dist_batch<OP, LPR>(p, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
+            const float mine = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
             F_TICK(4);
             vis_settle(cx.vis, bmask, e, vslot, vold);                               // the CAS results came back with the rows
             if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
@@ -197,7 +197,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             }
             unsigned long long km = ITER ? __ballot(lane < cnt) : __ballot(keep);     // ITER: rejected rows are visited too (they go to `discarded`)
             F_TICK(5);
-            __syncthreads();
+            F_BAR();
             while (km) {                                                             // replay in list order, mod.rs:226-243 / scan.rs:372-429
                 const uint32_t j = (uint32_t)__builtin_ctzll(km); km &= km - 1ull;
                 const uint2 it = cx.RES[j]; const float d = fh_d(it);
@@ -217,7 +217,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
                 }
             }
             if (ITER) d_flush();
-            __syncthreads();
+            F_BAR();
             F_TICK(6);
             cx.status = __shfl(cx.status, 0, 64);
             if (cx.status != FS_OK) break;
@@ -229,7 +229,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         cx.vcount = vcount;
     }
     if (lane == 0) cx.CTL[1] = wl;
-    __syncthreads();
+    F_BAR();
 }
 
 // stable sort of the W heap's internal array into EP: ascending (build, mod.rs:248-254) or descending (scan.rs:441-446);
@@ -245,18 +245,20 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
         }
         cx.EP[rank] = me;
     }
-    __syncthreads();
+    F_BAR();
 }
 
-template <class OP, int MODE, int LPR>   // MODE 0: query (get_scan_items), 1: insert (find_element_neighbors); LPR: lanes per row (64, or 8/32 for short rows)
-__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : FUSED_MINW))
-k_fused(const FusedParams p_in)
+// One search after the other, from the task counter, driven by ONE wavefront whose state lives in the LDS slot `lds` (`slot` selects its
+// visited table / spill area / discarded heap in global memory).  MODE 0: query (get_scan_items), 1: insert (find_element_neighbors),
+// 2: iterative scan; LPR: lanes per row (64, or 8/32 for short rows); POSTED: rows are evaluated by the workgroup's stream waves (k_fused2).
+template <class OP, int MODE, int LPR, bool POSTED>
+__device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *lds_base, const uint32_t slot, const uint32_t lane_in,
+                                         const uint32_t slot_bytes = 0, const uint32_t sq_off = 0, const uint32_t dout_off = 0, const uint32_t nc = 1, const uint32_t my_slot = 0)
 {
-    FusedParams p = p_in;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     FusedCtx cx;
+    cx.slot_bytes = slot_bytes; cx.sq_off = sq_off; cx.dout_off = dout_off; cx.nc = nc; cx.my_slot = my_slot;
     const uint32_t lm0 = 2u * p.m;
-    // LDS carve: C[ccap] | W[ef+2] | EP[ef+2] | RES[64] | RL[2m] | IDS[64] CTL[16] | QV[nch KiB].  The select phase runs
+    // LDS carve: C[ccap] | W[ef+2] | EP[ef+2] | RES[64] | RL[2m] | IDS[64] CTL[32] | dsc[64] | QV[nch KiB].  The select phase runs
     // after the layer's search is over, so its scratch (the candidate under test EV and the discarded list DL) reuses C.
     cx.C = (uint2 *)lds;
     cx.W = cx.C + p.clds;
@@ -265,27 +267,28 @@ k_fused(const FusedParams p_in)
     cx.RL = cx.RES + 64;
     cx.IDS = (uint32_t *)(cx.RL + lm0);
     cx.CTL = cx.IDS + 64;
-    p.dsc = (float *)(cx.CTL + 16);
+    p.dsc = (float *)(cx.CTL + 32);
+    cx.SQ = (volatile uint32_t *)(cx.CTL + 16); cx.DOUT = p.dsc; cx.lds_base = lds_base; cx.gen = 0;
     cx.QV = (uint8_t *)(p.dsc + 64);                      // query parked in LDS (nch KiB)
     cx.DP = (lds_uint2 *)(cx.QV + p.nch * 1024u);          // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
     cx.WS = cx.DP + 64; cx.LV = (uint32_t *)(cx.WS + 160);   // working set of a flush (<= 2*64 + depth entries), per-level {first index, offset}
     cx.DS.A = cx.WS + 160 + 32; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
-    cx.DS.G = MODE == 2 ? p.disc + (size_t)blockIdx.x * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
+    cx.DS.G = MODE == 2 ? p.disc + (size_t)slot * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
     cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
-    cx.CH.lds = (lds_uint2 *)cx.C; cx.CH.glob = p.spill + (size_t)blockIdx.x * p.spill_stride; cx.CH.L = p.clds;
+    cx.CH.lds = (lds_uint2 *)cx.C; cx.CH.glob = p.spill + (size_t)slot * p.spill_stride; cx.CH.L = p.clds;
     cx.WH.lds = (lds_uint2 *)cx.W; cx.WH.glob = nullptr; cx.WH.L = 0xffffffffu;
-    cx.lane = threadIdx.x;
-    cx.vis = p.vis + (size_t)blockIdx.x * p.vis_words;
+    cx.lane = lane_in;
+    cx.vis = p.vis + (size_t)slot * p.vis_words;
     cx.nd0 = cx.nd1 = 0; cx.cmax = 0;
     for (int i = 0; i < 14; i++) cx.tph[i] = 0;
     const uint32_t lane = cx.lane;
 
     for (;;) {
         if (lane == 0) cx.CTL[5] = atomicAdd(p.next_task, 1u);
-        __syncthreads();
+        F_BAR();
         const uint32_t t = cx.CTL[5];
-        __syncthreads();
+        F_BAR();
         if (t >= p.ntasks) break;
         cx.status = FS_OK;
         const uint32_t qsel = p.t_qsel[t];
@@ -299,21 +302,21 @@ k_fused(const FusedParams p_in)
 
         // d(q, entry point): mod.rs:371-377 / scan.rs:475
         if (lane == 0) cx.IDS[0] = p.entry;
-        __syncthreads();
-        const float d0 = f_dist_batch<OP, LPR>(p, cx.QV, cx.IDS, 1, lane);
+        F_BAR();
+        const float d0 = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, 1, lane);
         cx.nd0 += 1;
         if (lane == 0) cx.EP[0] = fh_pack(d0, p.entry);
-        __syncthreads();
+        F_BAR();
         uint32_t n_ep = 1;
 
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
         const int stop_above = MODE == 1 ? new_level : 0;
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
-            f_search_layer<OP, LPR>(p, cx, n_ep, 1u, lc, MODE != 1);
+            f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, 1u, lc, MODE != 1);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
                 f_sort_results(cx, wl, MODE != 1);
-                if (MODE != 1) { const uint2 best = cx.EP[wl - 1]; __syncthreads(); if (lane == 0) cx.EP[0] = best; __syncthreads(); }
+                if (MODE != 1) { const uint2 best = cx.EP[wl - 1]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); }
                 n_ep = 1;                         // MODE 1: ep = vec![w[0]]; EP[0] already is the nearest
             } else if (MODE != 1) { n_ep = 0; break; }
         }
@@ -335,7 +338,7 @@ k_fused(const FusedParams p_in)
                     while (left > 0 && outc < p.limit) {
                         const uint32_t c = left < 64u ? left : 64u, base = left - c;
                         if (lane < c) cx.IDS[lane] = p.emask[cx.EP[base + lane].y];
-                        __syncthreads();
+                        F_BAR();
                         for (uint32_t i = c; i-- > 0 && outc < p.limit;) {
                             const uint32_t em = cx.IDS[i]; const uint32_t nt = em >> 12;
                             if (nt == 0) continue;                                               // scan.rs:866-868
@@ -348,14 +351,14 @@ k_fused(const FusedParams p_in)
                                 outc++;
                             }
                         }
-                        __syncthreads();
+                        F_BAR();
                         left = base;
                     }
                     if (outc >= p.limit) break;
                     if (tuples >= p.max_tuples) {                                                // scan.rs:831-841: drain `discarded` one by one
                         if (cx.dlen == 0) break;
                         const uint2 one = PHeap<true>::pop(cx.DS, cx.dlen, lane);
-                        __syncthreads(); if (lane == 0) cx.EP[0] = one; __syncthreads();
+                        F_BAR(); if (lane == 0) cx.EP[0] = one; F_BAR();
                         single = true;
                         continue;
                     }
@@ -364,7 +367,7 @@ k_fused(const FusedParams p_in)
                     n_ep = 0;
                     while (n_ep < p.ef && cx.dlen > 0) {
                         const uint2 x = PHeap<true>::pop(cx.DS, cx.dlen, lane);
-                        __syncthreads(); if (lane == 0) cx.EP[n_ep] = x; __syncthreads();
+                        F_BAR(); if (lane == 0) cx.EP[n_ep] = x; F_BAR();
                         n_ep++;
                     }
                     f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, false, false);
@@ -374,7 +377,7 @@ k_fused(const FusedParams p_in)
         } else if (MODE == 0) {
             uint32_t cnt = 0;
             if (cx.status == FS_OK && n_ep > 0) {
-                f_search_layer<OP, LPR>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
+                f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, true);                                        // nearest LAST
                 cnt = wl < p.k ? wl : p.k;
@@ -390,7 +393,7 @@ k_fused(const FusedParams p_in)
             for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
             for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
                 const uint32_t lm = lc == 0 ? lm0 : p.m;
-                f_search_layer<OP, LPR>(p, cx, n_ep, p.ef, lc, false);                // mod.rs:407-416
+                f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, p.ef, lc, false);                // mod.rs:407-416
                 if (cx.status != FS_OK) break;
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
@@ -400,18 +403,18 @@ k_fused(const FusedParams p_in)
                     // next search), copied out coalesced.  d(new, x) there is the very value a back-link prune would recompute.
                     lds_uint2 *T = cx.CH.lds; const uint32_t tm = p.wt_size - 1u;
                     for (uint32_t i = lane; i < p.wt_size; i += 64) { T[i].x = 0u; T[i].y = VIS_EMPTY; }
-                    __syncthreads();
+                    F_BAR();
                     for (uint32_t i = lane; i < wl; i += 64) {
                         const uint2 e = cx.EP[i];
                         uint32_t s = vis_mix(e.y) & tm;
                         while (atomicCAS((uint32_t *)&T[s].y, VIS_EMPTY, e.y) != VIS_EMPTY) s = (s + 1u) & tm;
                         T[s].x = e.x;
                     }
-                    __syncthreads();
+                    F_BAR();
                     uint2 *dst = p.wtab + (size_t)(p.wt_slot0 + os) * p.wt_size;
                     for (uint32_t i = lane; i < p.wt_size; i += 64) dst[i] = make_uint2(T[i].x, T[i].y);
                     if (lane == 0 && p.wt_valid) p.wt_valid[p.wt_slot0 + os] = 1;
-                    __syncthreads();
+                    F_BAR();
                 }
                 // select_neighbors(W, lm): mod.rs:269-308
                 const unsigned long long ts0 = (p.fdbg & 4u) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -440,7 +443,7 @@ k_fused(const FusedParams p_in)
                         const uint2 e = cx.EP[i];
                         bool closer = true;                                          // check_element_closer, mod.rs:315-339
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // e's own row and list (requested one iteration ago) have landed
-                        __syncthreads();
+                        F_BAR();
                         const uint32_t my_id = nx_id; const float my_d = nx_d;       // e's list slot of this lane
                         if (i + 1u < wl) { const uint32_t en = cx.EP[i + 1u].y; f_park_async(p, p.rows + (size_t)en * p.pitch, lane, evb[(i + 1u) & 1u]); list_prefetch(en); }
                         if (r > 0 && i > 0) {
@@ -450,33 +453,65 @@ k_fused(const FusedParams p_in)
                         }
                         if (r > 0 && closer) {
                             if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
-                            __syncthreads();
-                            closer = !f_any_le<OP, LPR>(p, evb[i & 1u], cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
-                            __syncthreads();
+                            F_BAR();
+                            closer = !f_any_le_x<OP, LPR, POSTED>(p, cx, evb[i & 1u], cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
+                            F_BAR();
                         }
                         if (lane == 0) { if (closer) cx.RL[r] = e; else cx.DL[nd] = e; }
                         if (closer) r++; else nd++;
-                        __syncthreads();
+                        F_BAR();
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no row may still be in flight towards the query's slot
-                    __syncthreads();
+                    F_BAR();
                     f_park(p, qsrc, lane, cx.QV);                                    // the query again, for the next layer's search
                     if (lane == 0) for (uint32_t j = 0; j < nd && r < lm; j++) cx.RL[r++] = cx.DL[j];   // mod.rs:300-305
                     r = __shfl(r, 0, 64);
                 }
-                __syncthreads();
+                F_BAR();
                 const size_t lb = (size_t)os * p.o_lst + (size_t)lc * lm0;
                 for (uint32_t i = lane; i < r; i += 64) { const uint2 v = cx.RL[i]; p.out_ids[lb + i] = v.y; p.out_d[lb + i] = fh_d(v); }
                 if (lane == 0) p.out_cnt[obase + lc] = r;
-                __syncthreads();
+                F_BAR();
                 if (p.fdbg & 4u) cx.tph[13] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts0);
             }
             if (lane == 0) p.status[t] = cx.status;
         }
-        __syncthreads();
+        F_BAR();
     }
     if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax);
                      if (p.fdbg & 4u) { for (int i = 0; i < 14; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
+}
+
+template <class OP, int MODE, int LPR>
+__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : FUSED_MINW))
+k_fused(const FusedParams p_in)
+{
+    FusedParams p = p_in;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    f_worker<OP, MODE, LPR, false>(p, lds, lds, blockIdx.x, threadIdx.x);
+}
+
+// k_fused2: nc control waves (one search each, f_worker<POSTED>) + stream waves (f_stream_loop) per 1024-thread workgroup; see hx_fused_core.h
+template <class OP, int MODE>
+__global__ void __launch_bounds__(1024, 1)
+k_fused2(const FusedParams p_in, const uint32_t nc, const uint32_t slot_bytes)
+{
+    FusedParams p = p_in;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    volatile uint32_t *quit = (volatile uint32_t *)(lds + (size_t)nc * slot_bytes);
+    // offsets of a slot's StreamQ and distance outputs (the carve of f_worker)
+    const uint32_t ids_off = (p.clds + 2u * (p.ef + 2u) + 64u + 2u * p.m) * 8u, sq_off = ids_off + (64u + 16u) * 4u, dout_off = ids_off + (64u + 32u) * 4u;
+    if (threadIdx.x == 0) *quit = 0u;
+    if (wave < nc && lane < SQ_WORDS) *(volatile uint32_t *)(lds + (size_t)wave * slot_bytes + sq_off + lane * 4u) = 0u;
+    __syncthreads();                                               // the only workgroup barrier: the queues exist before anybody polls them
+    if (wave < nc) {
+        f_worker<OP, MODE, 64, true>(p, lds + (size_t)wave * slot_bytes, lds, blockIdx.x * nc + wave, lane, slot_bytes, sq_off, dout_off, nc, wave);
+        if (lane == 0) (void)__hip_atomic_fetch_add((uint32_t *)quit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        FusedParams ps = p; ps.dsc = nullptr;
+        f_stream_loop<OP>(ps, lds, slot_bytes, sq_off, dout_off, nc, quit, lane, wave - nc);
+    }
 }
 
 template <class OP, int MODE, int LPR>
@@ -495,6 +530,24 @@ static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid
     }
     hipLaunchKernelGGL((k_fused<OP, MODE, LPR>), dim3(grid), dim3(64), lds, e->stream, p);
     return hipGetLastError();
+}
+
+template <class OP, int MODE>
+static hipError_t launch_fused2(hx_engine *e, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes)
+{
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t s = hipFuncSetAttribute((const void *)k_fused2<OP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (s != hipSuccess) return s;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_fused2<OP, MODE>), dim3(grid), dim3(1024), (size_t)nc * slot_bytes + 64, e->stream, p, nc, slot_bytes);
+    return hipGetLastError();
+}
+template <class OP>
+static hipError_t launch_fused2_mode(hx_engine *e, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode)
+{
+    return mode == 0 ? launch_fused2<OP, 0>(e, p, grid, nc, slot_bytes) : launch_fused2<OP, 1>(e, p, grid, nc, slot_bytes);
 }
 
 template <class OP, int LPR>
