@@ -283,7 +283,7 @@ def test_c1_recall_config():
     rng = np.random.default_rng(1)
     n, dim, m, efc, efs, k = 10_000, 128, 16, 64, 40, 10
     rows = rng.random((n, dim), dtype=np.float32)
-    qs = rng.random((200, dim), dtype=np.float32)
+    qs = rng.random((1000, dim), dtype=np.float32)
     levels = hx.draw_levels(n, m, seed=1)
     e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
     e.append(rows)
@@ -293,13 +293,17 @@ def test_c1_recall_config():
     tids, d, _, cnt = ix.search(len(qs), efs, k)
     d2 = (qs.astype(np.float64) ** 2).sum(1)[:, None] + (rows.astype(np.float64) ** 2).sum(1)[None, :] - 2.0 * qs.astype(np.float64) @ rows.astype(np.float64).T
     exact = np.argsort(d2, axis=1)[:, :k]
-    recall = np.mean([len(set(tids[q, :cnt[q]].tolist()) & set(exact[q].tolist())) / k for q in range(len(qs))])
+    hits = np.array([len(set(tids[q, :cnt[q]].tolist()) & set(exact[q].tolist())) / k for q in range(len(qs))])
     o = orc.Index(orc.F32, orc.L2SQ, dim, m=m, ef_construction=efc, order=orc.SEQ)
     o.build(rows, levels, batch=1)
-    ref_recall = np.mean([len(set(t for t, _, _ in o.scan(qs[q], ef_search=efs, limit=k)) & set(exact[q].tolist())) / k for q in range(len(qs))])
-    # uniform 128-d data is a hard case (the reference's own gates use 3-d data): the bar is equality with the
-    # reference, 2000 samples => sigma ~ 0.011
-    assert abs(recall - ref_recall) <= 0.04, (recall, ref_recall)
+    ref_ids, ref_cnt = o.search_many(qs, efs, k, n_threads=8)
+    ref_hits = np.array([len(set(ref_ids[q, :ref_cnt[q]].tolist()) & set(exact[q].tolist())) / k for q in range(len(qs))])
+    recall, ref_recall = hits.mean(), ref_hits.mean()
+    # uniform 128-d data is a hard case (the reference's own gates use 3-d data): the bar is equality with the reference's schedule and
+    # summation order, query by query: the mean difference within 2 sigma of its sampling noise (+ 0.003)
+    diff = hits - ref_hits
+    sem = diff.std(ddof=1) / np.sqrt(len(diff))
+    assert abs(diff.mean()) <= 2.0 * sem + 0.003, (recall, ref_recall, diff.mean(), sem)
     assert recall >= 0.5
     ix.close()
     e.close()

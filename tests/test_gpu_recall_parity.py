@@ -1,0 +1,53 @@
+"""Recall parity of the batched device build against the REFERENCE schedule at a size where batching could matter.
+
+tests/golden/recall_parity_100k.json holds recall@10 of the oracle's strictly sequential build (one row at a time, the reference's own
+summation order) on 100 000 x vector(768) L2, m = 16, ef_construction = 200 -- BASELINE configs[1]'s shape; it was produced once on a CPU by
+tools/make_recall_fixture.py (10 minutes of one core) together with the hit count of every query.  Here the same rows, levels and
+queries go through the device build with the bench's batch cap (8192: 'snapshot' batches, a NON-reference schedule) and the device scan;
+the two graphs differ, so recall is compared query by query: the mean difference must vanish within 2 sigma of its own sampling noise
+(plus a 0.002 floor), at every ef_search of the fixture."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pgvector_rx_amd as hx
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_batched_device_build_recall_equals_sequential_reference_schedule(record_property):
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "recall_parity_100k.json")))
+    spec = importlib.util.spec_from_file_location("make_recall_fixture", os.path.join(ROOT, "tools", "make_recall_fixture.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                                       # the committed generator: same numpy streams as the fixture run
+    rows, qs = gen.make_data(fx)
+    n, dim, k = fx["rows"], fx["dim"], fx["k"]
+    levels = hx.draw_levels(n, fx["m"], seed=fx["seed_levels"])
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+    e.append(rows)
+    ix = hx.Index(e, fx["m"], fx["ef_construction"])
+    ix.insert(0, levels, batch=8192)
+    assert ix.fused_stats()["redone"] == 0
+    import torch
+    r, q = torch.from_numpy(rows).cuda().double(), torch.from_numpy(qs).cuda().double()
+    d = (r * r).sum(1)[None, :] - 2.0 * q @ r.T
+    gt = torch.topk(d, k, dim=1, largest=False).indices.cpu().numpy()
+    del r, q, d
+    e.set_queries(qs)
+    for efs, ref in fx["recall_at_k"].items():
+        tids, _, _, cnt = ix.search(len(qs), int(efs), k)
+        dev_hits = np.array([len(set(tids[i, :cnt[i]].tolist()) & set(gt[i].tolist())) for i in range(len(qs))], np.float64)
+        ref_hits = np.array([int(c, 16) for c in ref["hits_per_query"]], np.float64)
+        assert abs(ref_hits.mean() / k - ref["mean"]) < 1e-9
+        diff = (dev_hits - ref_hits) / k
+        sem = diff.std(ddof=1) / np.sqrt(len(diff))
+        record_property("ef_search_%s" % efs, {"device": dev_hits.mean() / k, "reference_schedule": ref["mean"], "diff": diff.mean(), "sem": sem})
+        print("\nef_search %s: recall@%d device (batch 8192) %.4f, sequential reference schedule %.4f, paired difference %+.4f +- %.4f"
+              % (efs, k, dev_hits.mean() / k, ref["mean"], diff.mean(), sem))
+        assert abs(diff.mean()) <= 2.0 * sem + 0.002, (efs, diff.mean(), sem)
+    ix.close()
+    e.close()
