@@ -125,6 +125,14 @@ int hx_pairwise_many(hx_engine *e, uint32_t n_groups, const uint32_t *group_offs
                      const uint16_t *na, const uint16_t *nb, const uint32_t *ids,
                      const uint64_t *out_offsets, float *out);
 
+/* The same pair blocks on the matrix cores (v_mfma_f32_32x32x16_f16), halfvec inner product only: BASELINE configs[3]'s "fp16 MFMA
+ * batched-build distance GEMM".  Products of halves are exact in f32, so a value differs from hx_pairwise_many's only by the order of
+ * the f32 additions: |delta| <= 2 * dim * 2^-24 * |a| |b|; norm2_out (nullable, one float per entry of ids) receives |row|^2 for
+ * that bound.  hx_index_set_mfma makes the graph driver use these values for the decisions of check_element_closer
+ * (graph/mod.rs:333) that fall outside the band and re-evaluate the others exactly, so graphs stay identical. */
+int hx_pairwise_many_mfma(hx_engine *e, uint32_t n_groups, const uint32_t *group_offsets, const uint16_t *na, const uint16_t *nb,
+                          const uint32_t *ids, const uint64_t *out_offsets, float *out, float *norm2_out);
+
 /* Byte equality of row pairs (the datumIsEqual-style duplicate test, build.rs:491-500). */
 int hx_rows_equal(hx_engine *e, uint32_t n_pairs, const uint32_t *a_ids, const uint32_t *b_ids, uint8_t *equal_out);
 
@@ -133,7 +141,7 @@ int hx_rows_equal(hx_engine *e, uint32_t n_pairs, const uint32_t *a_ids, const u
 int hx_set_timing(hx_engine *e, int enabled);
 int hx_last_kernel_ms(hx_engine *e, float *ms);
 /* Accumulated since the last reset, while timing is enabled: kind 0 = query-vs-rows kernel (units =
- * distances), kind 1 = pair-block kernel (units = pairs). */
+ * distances), kind 1 = pair-block kernel (units = pairs), 2 = traversal kernel, 3 = back-link kernels, 4 = MFMA pair kernel (units = pairs). */
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset);
 
 /* ------------------------------------------------------------------------------------------------
@@ -246,6 +254,10 @@ int hx_index_counters(const hx_index *ix, uint64_t counters_out[8]);
  * lock-step host driver.  disabled: everything runs in the lock-step driver.  Both produce identical results.
  * fused_stats: tasks given to the fused kernel and how many of them had to be re-run. */
 int hx_index_set_fused(hx_index *ix, int enabled);
+/* Lock-step placement, halfvec inner product: pair blocks of select_neighbors / back-link pruning on the matrix cores (hx_pairwise_many_mfma),
+ * in-band decisions re-evaluated in the canonical order.  stats: pairs evaluated by MFMA, pairs re-evaluated exactly. */
+int hx_index_set_mfma(hx_index *ix, int enabled);
+int hx_index_mfma_stats(const hx_index *ix, uint64_t *mfma_pairs, uint64_t *exact_pairs);
 int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone);
 
 /* host-side wall time of the lock-step driver since the last reset, seconds: [0] task state machines,

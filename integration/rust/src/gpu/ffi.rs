@@ -67,6 +67,8 @@ extern "C" {
     pub fn hx_pairwise(e: *mut hx_engine, ids: *const u32, w: u32, out_wxw: *mut f32) -> c_int;
     pub fn hx_pairwise_many(e: *mut hx_engine, n_groups: u32, group_offsets: *const u32, na: *const u16, nb: *const u16,
                             ids: *const u32, out_offsets: *const u64, out: *mut f32) -> c_int;
+    pub fn hx_pairwise_many_mfma(e: *mut hx_engine, n_groups: u32, group_offsets: *const u32, na: *const u16, nb: *const u16,
+                                 ids: *const u32, out_offsets: *const u64, out: *mut f32, norm2_out: *mut f32) -> c_int;
     pub fn hx_rows_equal(e: *mut hx_engine, n_pairs: u32, a_ids: *const u32, b_ids: *const u32, equal_out: *mut u8) -> c_int;
     pub fn hx_set_timing(e: *mut hx_engine, enabled: c_int) -> c_int;
     pub fn hx_last_kernel_ms(e: *mut hx_engine, ms: *mut f32) -> c_int;
@@ -117,6 +119,8 @@ extern "C" {
     pub fn hx_index_set_neighbors(ix: *mut hx_index, elem: u32, layer: c_int, count: u32, ids: *const u32, dist: *const f32) -> c_int;
     pub fn hx_index_counters(ix: *const hx_index, counters_out: *mut u64) -> c_int;
     pub fn hx_index_set_fused(ix: *mut hx_index, enabled: c_int) -> c_int;
+    pub fn hx_index_set_mfma(ix: *mut hx_index, enabled: c_int) -> c_int;
+    pub fn hx_index_mfma_stats(ix: *const hx_index, mfma_pairs: *mut u64, exact_pairs: *mut u64) -> c_int;
     pub fn hx_index_fused_stats(ix: *const hx_index, tasks: *mut u64, redone: *mut u64) -> c_int;
     pub fn hx_index_profile(ix: *const hx_index, seconds_out: *mut f64, reset: c_int) -> c_int;
     // scans

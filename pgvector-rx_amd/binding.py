@@ -54,6 +54,7 @@ def lib():
         "hx_distances_batch": (i32, [vp, u32, vp, vp, vp, vp]),
         "hx_pairwise": (i32, [vp, vp, u32, vp]),
         "hx_pairwise_many": (i32, [vp, u32, vp, vp, vp, vp, vp, vp]),
+        "hx_pairwise_many_mfma": (i32, [vp, u32, vp, vp, vp, vp, vp, vp, vp]),
         "hx_rows_equal": (i32, [vp, u32, vp, vp, vp]),
         "hx_set_timing": (i32, [vp, i32]),
         "hx_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
@@ -97,6 +98,8 @@ def lib():
         "hx_index_counters": (i32, [vp, vp]),
         "hx_index_profile": (i32, [vp, vp, i32]),
         "hx_index_set_fused": (i32, [vp, i32]),
+        "hx_index_set_mfma": (i32, [vp, i32]),
+        "hx_index_mfma_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_fused_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
         "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
@@ -207,9 +210,10 @@ class Engine:
         self._ck(lib().hx_pairwise(self.h, _p(ids), len(ids), _p(out)))
         return out
 
-    def pairwise_many(self, groups):
+    def pairwise_many(self, groups, mfma=False):
         """groups: list of (A_ids, B_ids or None).  Returns one array per group: packed lower triangle
-        (B None) or an (na, nb) rectangle."""
+        (B None) or an (na, nb) rectangle.  mfma: on the matrix cores (halfvec inner product; values in MFMA summation order);
+        then also returns |row|^2 per id (concatenated A then B ids of every group)."""
         off, na, nb, ids, ooff, n_out = [0], [], [], [], [], 0
         for a, b in groups:
             b = [] if b is None else b
@@ -224,14 +228,18 @@ class Engine:
         na, nb = np.asarray(na, np.uint16), np.asarray(nb, np.uint16)
         ooff_a = np.asarray(ooff, np.uint64)
         out = np.empty(max(n_out, 1), np.float32)
-        self._ck(lib().hx_pairwise_many(self.h, len(groups), _p(off), _p(na), _p(nb), _p(ids), _p(ooff_a), _p(out)))
+        norm2 = np.empty(len(ids), np.float32) if mfma else None
+        if mfma:
+            self._ck(lib().hx_pairwise_many_mfma(self.h, len(groups), _p(off), _p(na), _p(nb), _p(ids), _p(ooff_a), _p(out), _p(norm2)))
+        else:
+            self._ck(lib().hx_pairwise_many(self.h, len(groups), _p(off), _p(na), _p(nb), _p(ids), _p(ooff_a), _p(out)))
         res = []
         for g, (a, b) in enumerate(groups):
             if b is None or len(b) == 0:
                 res.append(out[ooff[g]:ooff[g] + len(a) * (len(a) - 1) // 2].copy())
             else:
                 res.append(out[ooff[g]:ooff[g] + len(a) * len(b)].reshape(len(a), len(b)).copy())
-        return res
+        return (res, norm2) if mfma else res
 
     def rows_equal(self, a_ids, b_ids):
         a, b = _u32(a_ids), _u32(b_ids)
@@ -466,6 +474,14 @@ class Index:
 
     def set_fused(self, on):
         self._ck(lib().hx_index_set_fused(self.h, int(on)))
+
+    def set_mfma(self, on):
+        self._ck(lib().hx_index_set_mfma(self.h, int(on)))
+
+    def mfma_stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(lib().hx_index_mfma_stats(self.h, C.byref(a), C.byref(b)))
+        return {"mfma_pairs": a.value, "exact_pairs": b.value}
 
     def fused_stats(self):
         a, b = C.c_uint64(), C.c_uint64()

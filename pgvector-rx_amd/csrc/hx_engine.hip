@@ -301,6 +301,8 @@ int hx_engine::layout_round(const HxRound &r)
     const size_t o_pg_nb = o;      o = al16(o + (size_t)r.n_pgroups * 2);
     const size_t o_pids = o;       o = al16(o + (size_t)r.n_pids * 4);
     const size_t o_wg = o;         o = al16(o + (size_t)c.max_wgs * 8);
+    const size_t o_glist = o;      o = al16(o + (size_t)r.n_pgroups * 4);
+    const size_t o_flag = o;       o = al16(o + (size_t)r.n_pgroups);
     c.req_bytes = o;
     const size_t o_out = 0, o_pout = al16((size_t)r.n_dids * 4);
     c.res_bytes = al16(o_pout + (size_t)r.n_pout * 4);
@@ -325,7 +327,9 @@ int hx_engine::layout_round(const HxRound &r)
 #define HX_SUB(T, name, off) c.h_##name = (T *)(c.h_req + (off)); c.d_##name = (T *)(c.d_req + (off))
     HX_SUB(uint32_t, grp_q, o_grp_q); HX_SUB(uint32_t, grp_off, o_grp_off); HX_SUB(uint32_t, ids, o_ids);
     HX_SUB(uint32_t, pg_off, o_pg_off); HX_SUB(uint64_t, pg_out_off, o_pg_out); HX_SUB(uint16_t, pg_na, o_pg_na);
-    HX_SUB(uint16_t, pg_nb, o_pg_nb); HX_SUB(uint32_t, pids, o_pids); HX_SUB(uint32_t, wg_tab, o_wg);
+    HX_SUB(uint16_t, pg_nb, o_pg_nb); HX_SUB(uint32_t, pids, o_pids); HX_SUB(uint32_t, wg_tab, o_wg); HX_SUB(uint32_t, glist, o_glist);
+    c.h_pg_flag = c.h_req + o_flag;
+    if (r.n_pgroups) memset(c.h_pg_flag, 0, r.n_pgroups);
 #undef HX_SUB
     c.h_out = (float *)(c.h_res + o_out); c.d_out = (float *)(c.d_res + o_out);
     c.h_pout = (float *)(c.h_res + o_pout); c.d_pout = (float *)(c.d_res + o_pout);
@@ -337,13 +341,15 @@ int hx_engine::run_round()
     HxChannel &c = ch;
     const HxRound &r = c.round;
     const bool do_dist = r.n_dgroups > 0 && r.n_dids > 0;
-    // workgroup table + LDS rows of the pair launch
-    uint32_t n_wgs = 0, lds_rows = 1;
+    // workgroup table + LDS rows of the pair launch; groups flagged for the matrix cores get one workgroup each in their own launch
+    uint32_t n_wgs = 0, lds_rows = 1, n_mf = 0;
     if (r.n_pgroups > 0 && r.n_pout > 0) {
         for (uint32_t g = 0; g < r.n_pgroups; g++) {
             const uint32_t na = c.h_pg_na[g], nb = c.h_pg_nb[g];
             if (na + nb > HX_PAIR_MAX_ROWS) return fail(HX_E_ARG, "pair group exceeds HX_PAIR_MAX_ROWS");
             const uint32_t P = nb ? na * nb : na * (na - 1) / 2;
+            if (P == 0) continue;
+            if (c.h_pg_flag[g]) { c.h_glist[n_mf++] = g; continue; }
             lds_rows = std::max(lds_rows, na + nb);
             for (uint32_t p0 = 0; p0 < P; p0 += HX_PAIR_SLAB) {
                 if (n_wgs >= c.max_wgs) return fail(HX_E_STATE, "pair workgroup table overflow");
@@ -351,7 +357,8 @@ int hx_engine::run_round()
             }
         }
     }
-    if (!do_dist && n_wgs == 0) return HX_OK;
+    if (n_mf && (dtype != HX_F16 || metric != HX_NEG_IP)) return fail(HX_E_ARG, "the MFMA pair path serves halfvec inner product");
+    if (!do_dist && n_wgs == 0 && n_mf == 0) return HX_OK;
     HX_HIP(this, hipMemcpyAsync(c.d_req, c.h_req, c.req_bytes, hipMemcpyHostToDevice, stream));
     if (do_dist) {
         if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
@@ -374,9 +381,16 @@ int hx_engine::run_round()
         HX_HIP(this, ls);
         if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
     }
+    if (n_mf) {
+        if (timing) HX_HIP(this, hipEventRecord(ev4, stream));
+        HX_HIP(this, hx_launch_pair_mfma(this, n_mf, c.d_glist));
+        if (timing) HX_HIP(this, hipEventRecord(ev5, stream));
+    }
     HX_HIP(this, hipMemcpyAsync(c.h_res, c.d_res, c.res_bytes, hipMemcpyDeviceToHost, stream));
     HX_HIP(this, hipStreamSynchronize(stream));
     if (timing) {
+        if (n_mf) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev4, ev5)); uint64_t np = 0; for (uint32_t k = 0; k < n_mf; k++) { const uint32_t g = c.h_glist[k]; const uint32_t na = c.h_pg_na[g], nb = c.h_pg_nb[g]; np += nb ? (uint64_t)na * nb : (uint64_t)na * (na - 1) / 2; }
+                    stat_mfma.launches++; stat_mfma.units += np; stat_mfma.ms += ms; }
         if (do_dist) { HX_HIP(this, hipEventElapsedTime(&last_ms, ev0, ev1)); stat_dist.launches++; stat_dist.units += r.n_dids; stat_dist.ms += last_ms; }
         if (n_wgs) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_pair.launches++; stat_pair.units += r.n_pout; stat_pair.ms += ms; }
     }
@@ -426,6 +440,8 @@ int hx_create(int device, int dtype, int metric, int dim, uint64_t capacity_rows
     CREATE_HIP(hipEventCreate(&e->ev1));
     CREATE_HIP(hipEventCreate(&e->ev2));
     CREATE_HIP(hipEventCreate(&e->ev3));
+    CREATE_HIP(hipEventCreate(&e->ev4));
+    CREATE_HIP(hipEventCreate(&e->ev5));
     s = hipMalloc((void **)&e->d_rows, e->capacity * e->pitch);
     if (s != hipSuccess) { hx_destroy(e); return create_fail(HX_E_NOMEM, "cannot reserve row store in HBM"); }
     e->cap_queries = 64;
@@ -446,13 +462,15 @@ int hx_destroy(hx_engine *e)
     HxMirror &mr = e->mirror;
     void *hp[] = {c.h_req, c.h_res, mr.h_stage, mr.h_io, mr.h_lk, e->grp.h_ctr, e->grp.h, e->bw.h, e->bw.h_ctr};
     void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries, mr.d_l0_ids, mr.d_l0_d, mr.d_l0_cnt, mr.d_level, mr.d_up_block, mr.d_up_ids, mr.d_up_d, mr.d_up_cnt, mr.d_vis, mr.d_stage, mr.d_io, mr.d_lk, mr.d_pm, mr.d_pm_valid, mr.d_spill,
-                  mr.d_disc, mr.d_emask, mr.d_spill_big, mr.d_vis_big, e->grp.d, e->bw.d, e->bw.d_rec, e->d_xl, e->bw.d_wtab, e->bw.d_wt_valid};
+                  mr.d_disc, mr.d_emask, mr.d_spill_big, mr.d_vis_big, e->grp.d, e->bw.d, e->bw.d_rec, e->d_xl, e->bw.d_wtab, e->bw.d_wt_valid, e->d_mf_norm2};
     for (void *p : hp) if (p) (void)hipHostFree(p);
     for (void *p : dp) if (p) (void)hipFree(p);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev2) (void)hipEventDestroy(e->ev2);
     if (e->ev3) (void)hipEventDestroy(e->ev3);
+    if (e->ev4) (void)hipEventDestroy(e->ev4);
+    if (e->ev5) (void)hipEventDestroy(e->ev5);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return HX_OK;
@@ -630,6 +648,43 @@ int hx_pairwise_many(hx_engine *e, uint32_t n_groups, const uint32_t *group_offs
     return HX_OK;
 }
 
+// The same pair blocks on the matrix cores (halfvec inner product only): values in MFMA summation order, i.e. within
+// 2 * dim * 2^-24 * |a| |b| of hx_pairwise_many's; norm2_out (nullable, one per id) receives |row|^2 for that bound.
+int hx_pairwise_many_mfma(hx_engine *e, uint32_t n_groups, const uint32_t *group_offsets, const uint16_t *na, const uint16_t *nb, const uint32_t *ids,
+                          const uint64_t *out_offsets, float *out, float *norm2_out)
+{
+    if (!e) return HX_E_ARG;
+    if (n_groups == 0) return HX_OK;
+    if (!group_offsets || !na || !nb || !ids || !out_offsets || !out) return e->fail(HX_E_ARG, "NULL argument");
+    if (e->dtype != HX_F16 || e->metric != HX_NEG_IP) return e->fail(HX_E_ARG, "the MFMA pair path serves halfvec inner product");
+    const uint32_t n_ids = group_offsets[n_groups];
+    int rc;
+    if ((rc = check_ids(e, ids, n_ids))) return rc;
+    uint64_t n_out = 0;
+    for (uint32_t g = 0; g < n_groups; g++) {
+        if (group_offsets[g + 1] - group_offsets[g] != (uint32_t)na[g] + nb[g]) return e->fail(HX_E_ARG, "group_offsets disagree with na+nb");
+        if ((uint32_t)na[g] + nb[g] > HX_PAIR_MAX_ROWS) return e->fail(HX_E_ARG, "pair group exceeds HX_PAIR_MAX_ROWS");
+        const uint64_t P = nb[g] ? (uint64_t)na[g] * nb[g] : (uint64_t)na[g] * (na[g] ? na[g] - 1 : 0) / 2;
+        n_out = std::max(n_out, out_offsets[g] + P);
+    }
+    HX_HIP(e, hipSetDevice(e->device));
+    HxRound r; r.n_pgroups = n_groups; r.n_pids = n_ids; r.n_pout = n_out;
+    if ((rc = e->layout_round(r))) return rc;
+    memcpy(e->ch.h_pg_off, group_offsets, (n_groups + 1) * sizeof(uint32_t));
+    memcpy(e->ch.h_pg_na, na, n_groups * sizeof(uint16_t));
+    memcpy(e->ch.h_pg_nb, nb, n_groups * sizeof(uint16_t));
+    memcpy(e->ch.h_pg_out_off, out_offsets, n_groups * sizeof(uint64_t));
+    memcpy(e->ch.h_pids, ids, n_ids * sizeof(uint32_t));
+    memset(e->ch.h_pg_flag, 1, n_groups);
+    if ((rc = e->run_round())) return rc;
+    memcpy(out, e->ch.h_pout, n_out * sizeof(float));
+    if (norm2_out) {
+        if ((rc = e->mfma_norms(e->n_rows))) return rc;
+        for (uint32_t i = 0; i < n_ids; i++) norm2_out[i] = e->h_mf_norm2[ids[i]];
+    }
+    return HX_OK;
+}
+
 int hx_pairwise(hx_engine *e, const uint32_t *ids, uint32_t w, float *out)
 {
     if (!e) return HX_E_ARG;
@@ -715,7 +770,7 @@ int hx_last_kernel_ms(hx_engine *e, float *ms) { if (!e || !ms) return HX_E_ARG;
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset)
 {
     if (!e) return HX_E_ARG;
-    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : kind == 2 ? e->stat_fused : e->stat_links;
+    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : kind == 2 ? e->stat_fused : kind == 3 ? e->stat_links : e->stat_mfma;
     if (launches) *launches = s.launches;
     if (units) *units = s.units;
     if (ms) *ms = s.ms;

@@ -166,7 +166,7 @@ static void stable_sort_desc(std::vector<Cand> &v) { std::stable_sort(v.begin(),
 // ------------------------------------------------------------------------------------------------
 // lock-step task protocol
 // ------------------------------------------------------------------------------------------------
-struct PairGroup { uint16_t na, nb; };
+struct PairGroup { uint16_t na, nb; uint8_t mfma = 0; };   // mfma: evaluate on the matrix cores (hx_mfma.hip), values within a known band of the canonical ones
 
 struct LsTask {
     // request produced by advance(): at most one distance group and any number of pair groups
@@ -263,10 +263,16 @@ struct SelectTask {
     size_t pos = 0, blk = 0, r0 = 0;
     bool finished = true;
     static constexpr size_t FIRST_BLOCK = 48, NEXT_BLOCK = 32, RCHUNK = 32;
+    // MFMA mode (halfvec inner product): the block's pair values come from the matrix cores first; a decision `d(e, r) <= d(e, q)` (mod.rs:333)
+    // whose two sides are closer than the summation-order band is re-requested in the canonical order before the block is processed
+    bool mfma = false; const float *norm2 = nullptr; float band_k = 0.0f;
+    int phase = 0;                          // 1: approximate values requested, 2: exact fix-ups requested
+    std::vector<float> vals; std::vector<uint32_t> fix;
+    uint64_t n_mfma = 0, n_exact = 0;
 
     void start(const std::vector<Cand> *c, size_t maxn_)
     {
-        cands = c; maxn = maxn_; R.clear(); disc.clear(); r_blk.clear(); pos = 0; blk = 0; r0 = 0; finished = false;
+        cands = c; maxn = maxn_; R.clear(); disc.clear(); r_blk.clear(); pos = 0; blk = 0; r0 = 0; finished = false; phase = 0;
         if (c->size() <= maxn) { R = *c; finished = true; }                          // mod.rs:276-278
     }
     // posts the pair groups of the next block into t; returns false when there is nothing left to ask
@@ -279,13 +285,13 @@ struct SelectTask {
         blk = std::min(n - pos, r0 == 0 ? FIRST_BLOCK : NEXT_BLOCK);
         for (auto &x : r_blk) x = -1;
         if (blk >= 2) {                                                              // triangle inside the block
-            t.pgroups.push_back(PairGroup{(uint16_t)blk, 0});
+            t.pgroups.push_back(PairGroup{(uint16_t)blk, 0, (uint8_t)mfma});
             for (size_t k = 0; k < blk; k++) t.pair_ids.push_back((*cands)[pos + k].id);
             t.n_pair += blk * (blk - 1) / 2;
         }
         for (size_t c0 = 0; c0 < r0; c0 += RCHUNK) {                                 // block x (R as of block start)
             const size_t nbk = std::min(RCHUNK, r0 - c0);
-            t.pgroups.push_back(PairGroup{(uint16_t)blk, (uint16_t)nbk});
+            t.pgroups.push_back(PairGroup{(uint16_t)blk, (uint16_t)nbk, (uint8_t)mfma});
             for (size_t k = 0; k < blk; k++) t.pair_ids.push_back((*cands)[pos + k].id);
             for (size_t j = 0; j < nbk; j++) t.pair_ids.push_back(R[c0 + j].id);
             t.n_pair += blk * nbk;
@@ -294,7 +300,58 @@ struct SelectTask {
             process_block(nullptr);
             return post(t);
         }
+        if (mfma) phase = 1;
         return true;
+    }
+    // consumes the results of the previous request (if any) and posts the next one; false: select_neighbors is complete
+    bool step(const float *pres, LsTask &t)
+    {
+        if (pres) {
+            if (!mfma) process_block(pres);
+            else if (phase == 1) {
+                const size_t n_tri = blk >= 2 ? blk * (blk - 1) / 2 : 0;
+                size_t n_all = n_tri;
+                for (size_t c0 = 0; c0 < r0; c0 += RCHUNK) n_all += blk * std::min(RCHUNK, r0 - c0);
+                vals.assign(pres, pres + n_all); n_mfma += n_all;
+                // pairs whose decision the summation order could flip: |value - threshold| within the band
+                fix.clear();
+                auto in_band = [&](size_t idx, const Cand &a, uint32_t b_id) {
+                    const float band = band_k * std::sqrt(norm2[a.id] * norm2[b_id]);
+                    return std::fabs(vals[idx] - a.d) <= band;
+                };
+                for (size_t k = 0; k < blk; k++) {
+                    const Cand &a = (*cands)[pos + k];
+                    const size_t first = fix.size();
+                    for (size_t kk = 0; kk < k; kk++) if (in_band(k * (k - 1) / 2 + kk, a, (*cands)[pos + kk].id)) fix.push_back((uint32_t)(k * (k - 1) / 2 + kk));
+                    size_t base = n_tri;
+                    for (size_t c0 = 0; c0 < r0; c0 += RCHUNK) {
+                        const size_t nbk = std::min(RCHUNK, r0 - c0);
+                        for (size_t j = 0; j < nbk; j++) if (in_band(base + k * nbk + j, a, R[c0 + j].id)) fix.push_back((uint32_t)(base + k * nbk + j));
+                        base += blk * nbk;
+                    }
+                    // exact request for row a against its in-band partners: 1 x nb rectangles (<= 63 partners each)
+                    for (size_t f0 = first; f0 < fix.size(); f0 += 63) {
+                        const size_t nbk = std::min<size_t>(63, fix.size() - f0);
+                        t.pgroups.push_back(PairGroup{1, (uint16_t)nbk, 0});
+                        t.pair_ids.push_back(a.id);
+                        for (size_t f = f0; f < f0 + nbk; f++) {
+                            const size_t idx = fix[f];
+                            uint32_t b_id;
+                            if (idx < n_tri) b_id = (*cands)[pos + (idx - k * (k - 1) / 2)].id;
+                            else { size_t rem = idx - n_tri, c0 = 0; for (;; c0 += RCHUNK) { const size_t nbk2 = std::min(RCHUNK, r0 - c0); if (rem < blk * nbk2) { b_id = R[c0 + rem % nbk2].id; break; } rem -= blk * nbk2; } }
+                            t.pair_ids.push_back(b_id);
+                        }
+                        t.n_pair += nbk;
+                    }
+                }
+                if (!fix.empty()) { n_exact += fix.size(); phase = 2; return true; }
+                process_block(vals.data()); phase = 0;
+            } else if (phase == 2) {
+                for (size_t f = 0; f < fix.size(); f++) vals[fix[f]] = pres[f];      // the exact groups were posted in `fix` order, one value each
+                process_block(vals.data()); phase = 0;
+            }
+        }
+        return post(t);
     }
     void process_block(const float *res)
     {
@@ -371,8 +428,7 @@ struct InsertTask : LsTask {
                 st = S_SELECT; pres = nullptr;
                 break;
             case S_SELECT:                                                           // mod.rs:419-425
-                if (pres) { sel.process_block(pres); pres = nullptr; }
-                if (sel.post(*this)) return true;
+                { const float *pp = pres; pres = nullptr; if (sel.step(pp, *this)) return true; }
                 nb[lc] = sel.R;
                 ep = w;
                 lc--;
@@ -401,8 +457,7 @@ struct BacklinkTask : LsTask {
         const size_t lm = (size_t)g->lm(layer);
         for (;;) {
             if (selecting) {
-                if (pres) { sel.process_block(pres); pres = nullptr; }
-                if (sel.post(*this)) return true;
+                { const float *pp = pres; pres = nullptr; if (sel.step(pp, *this)) return true; }
                 Cand *lst = g->list(target, layer);
                 for (size_t i = 0; i < sel.R.size(); i++) lst[i] = sel.R[i];         // mod.rs:484-485
                 g->cnt(target, layer) = (uint16_t)sel.R.size();
@@ -704,6 +759,9 @@ struct hx_index {
     std::vector<std::unique_ptr<DiskNeighborsTask>> disk_pool;
     std::vector<std::unique_ptr<UpdateIndexTask>> update_pool;
     bool fused = true;                                         // device-resident traversal (hx_fused.inc.h) for searches
+    bool mfma = false; uint64_t mfma_pairs = 0, mfma_exact = 0; // lock-step select blocks on the matrix cores (halfvec inner product)
+    bool mfma_on() const { return mfma && e->dtype == HX_F16 && e->metric == HX_NEG_IP; }
+    void arm_select(SelectTask &sel) { sel.mfma = mfma_on(); sel.norm2 = e->h_mf_norm2.data(); sel.band_k = 2.0f * (float)e->dim * 5.9604645e-08f * 1.001f; sel.n_mfma = sel.n_exact = 0; }
     // index loaded from its page image (hx_index_load_pages): where each element tuple sits and the version it carried (types/hnsw.rs:120)
     std::vector<uint32_t> loc_blk; std::vector<uint16_t> loc_off; std::vector<uint8_t> loc_ver; std::unordered_map<uint64_t, uint32_t> loc2elem;
     std::vector<std::pair<uint32_t, int>> dirty;               // (element, layer) lists the device mirror has not seen yet
@@ -838,6 +896,7 @@ struct hx_index {
     {
         if (tasks.empty()) return HX_OK;
         { int rc0 = ensure_host_lists(); if (rc0) return rc0; }
+        if (mfma_on()) { int rc0 = e->mfma_norms(e->n_rows); if (rc0) return fail(rc0, e->err); }
         if (window == 0 || window > tasks.size()) window = tasks.size();
         std::vector<LsTask *> live(tasks.begin(), tasks.begin() + window), live2;
         size_t admitted = window;
@@ -904,7 +963,7 @@ struct hx_index {
                     if (!t->pgroups.empty()) {
                         memcpy(c.h_pids + o.pids, t->pair_ids.data(), t->pair_ids.size() * sizeof(uint32_t));
                         for (const PairGroup &pg : t->pgroups) {
-                            c.h_pg_off[o.pgroups] = (uint32_t)o.pids; c.h_pg_na[o.pgroups] = pg.na; c.h_pg_nb[o.pgroups] = pg.nb;
+                            c.h_pg_off[o.pgroups] = (uint32_t)o.pids; c.h_pg_na[o.pgroups] = pg.na; c.h_pg_nb[o.pgroups] = pg.nb; c.h_pg_flag[o.pgroups] = pg.mfma;
                             c.h_pg_out_off[o.pgroups] = o.pout; o.pgroups++;
                             o.pids += (size_t)pg.na + pg.nb;
                             o.pout += pg.nb ? (size_t)pg.na * pg.nb : (size_t)pg.na * (pg.na - 1) / 2;
@@ -1056,6 +1115,8 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
         InsertTask &t = *its[ti];
         t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
         t.g = &g; t.id = bs.base + i; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
+        if (ix->mfma_on()) { int rcn = ix->e->mfma_norms(ix->e->n_rows); if (rcn) return ix->fail(rcn, ix->e->err); }
+        ix->arm_select(t.sel);
         tasks[ti] = &t;
     }
     int rc = ix->run_lockstep(tasks);
@@ -1069,6 +1130,7 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
             g.cnt(t.id, lc) = (uint16_t)t.nb[lc].size();
         }
         ix->counters[1] += t.n_dist; ix->counters[2] += t.n_pair;
+        ix->mfma_pairs += t.sel.n_mfma; ix->mfma_exact += t.sel.n_exact;
         ix->mark_dirty(t.id);
         bs.searched[i] = 1;
     }
@@ -1277,11 +1339,13 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         BacklinkTask &bt = *bts[nbt++];
         bt.k = 0; bt.selecting = false; bt.n_dist = bt.n_pair = 0; bt.clear_req();
         bt.g = &g; bt.target = ops[gr.first].target; bt.layer = ops[gr.first].layer; bt.ops.assign(ops.begin() + gr.first, ops.begin() + gr.second);
+        if (ix->mfma_on()) { int rcn = ix->e->mfma_norms(ix->e->n_rows); if (rcn) return ix->fail(rcn, ix->e->err); }
+        ix->arm_select(bt.sel);
         btasks.push_back(&bt);
     }
     ix->prof[8] += hx_index::now_s() - t_links0;      // duplicates + op grouping + task setup
     { hx_index::Timer tl(ix->prof[9]); if ((rc = ix->run_lockstep(btasks))) return rc; }
-    for (size_t i = 0; i < nbt; i++) { ix->counters[3] += bts[i]->n_pair; ix->dirty.emplace_back(bts[i]->target, bts[i]->layer); }
+    for (size_t i = 0; i < nbt; i++) { ix->counters[3] += bts[i]->n_pair; ix->mfma_pairs += bts[i]->sel.n_mfma; ix->mfma_exact += bts[i]->sel.n_exact; ix->dirty.emplace_back(bts[i]->target, bts[i]->layer); }
     bs.linked = true;
     return HX_OK;
 }
@@ -1438,6 +1502,8 @@ int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_recor
         InsertTask &t = *its[ti];
         t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
         t.g = &g; t.id = bs.base + lo + todo[ti]; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
+        if (ix->mfma_on()) { int rcn = ix->e->mfma_norms(ix->e->n_rows); if (rcn) return ix->fail(rcn, ix->e->err); }
+        ix->arm_select(t.sel);
         tasks[ti] = &t;
     }
     if ((rc = ix->run_lockstep(tasks))) return rc;
@@ -1890,6 +1956,20 @@ int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t coun
 }
 
 int hx_index_set_fused(hx_index *ix, int enabled) { if (!ix) return HX_E_ARG; ix->fused = enabled != 0; return HX_OK; }
+int hx_index_set_mfma(hx_index *ix, int enabled)
+{
+    if (!ix) return HX_E_ARG;
+    if (enabled && (ix->e->dtype != HX_F16 || ix->e->metric != HX_NEG_IP)) return ix->fail(HX_E_ARG, "the MFMA pair path serves halfvec inner product");
+    ix->mfma = enabled != 0;
+    return HX_OK;
+}
+int hx_index_mfma_stats(const hx_index *ix, uint64_t *mfma_pairs, uint64_t *exact_pairs)
+{
+    if (!ix) return HX_E_ARG;
+    if (mfma_pairs) *mfma_pairs = ix->mfma_pairs;
+    if (exact_pairs) *exact_pairs = ix->mfma_exact;
+    return HX_OK;
+}
 int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone)
 {
     if (!ix) return HX_E_ARG;

@@ -27,6 +27,7 @@ struct HxChannel {
     float *h_out = nullptr, *d_out = nullptr;
     // pair groups (hx_pairwise_many shape); wg_tab: {group, first pair} per workgroup
     uint32_t *h_pg_off = nullptr, *h_pids = nullptr, *h_wg_tab = nullptr;
+    uint8_t *h_pg_flag = nullptr; uint32_t *h_glist = nullptr, *d_glist = nullptr;   // per group: 1 = evaluate on the matrix cores (hx_mfma.hip); the list of those groups
     uint16_t *h_pg_na = nullptr, *h_pg_nb = nullptr;
     uint64_t *h_pg_out_off = nullptr;
     uint32_t *d_pg_off = nullptr, *d_pids = nullptr, *d_wg_tab = nullptr;
@@ -99,7 +100,11 @@ struct hx_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timing = false; float last_ms = 0.f;
-    HxKernelStat stat_dist, stat_pair, stat_fused, stat_links;
+    HxKernelStat stat_dist, stat_pair, stat_fused, stat_links, stat_mfma;
+    hipEvent_t ev4 = nullptr, ev5 = nullptr;
+    // |row|^2 of halfvec rows for the MFMA band (hx_mfma.hip)
+    float *d_mf_norm2 = nullptr; uint64_t mf_cap = 0, mf_norm_rows = 0; std::vector<float> h_mf_norm2;
+    int mfma_norms(uint64_t upto);
     HxMirror mirror;
     uint64_t fused_cmax = 0;      // largest candidate-heap length any fused task reached (sizing the LDS budget)
     HxChannel ch;
@@ -144,6 +149,8 @@ struct hx_engine {
                   uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr, uint32_t roomy = 1, const HxFusedDev *dev = nullptr);   // roomy > 1: retry of overflowed tasks with that many times the visited table and candidate heap
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
+
+hipError_t hx_launch_pair_mfma(hx_engine *e, uint32_t n_groups, const uint32_t *d_glist);
 
 #define HX_HIP(e, call)                                                                             \
     do {                                                                                            \
