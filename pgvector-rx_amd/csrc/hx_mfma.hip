@@ -41,27 +41,39 @@ k_pair_mfma_f16(const uint8_t *__restrict__ rows, uint32_t pitch, uint32_t dim,
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     const uint32_t nsteps = (dim + 63u) / 64u;                    // super-steps of 64 halves: lane half h owns bytes [128 t + 64 h, + 64)
+    const uint32_t nfull = pitch / 128u;                          // super-steps that lie inside the row for every lane
+    // loads are issued unconditionally (a lane past the row re-reads its first bytes) and masked only where they are consumed, in the one
+    // ragged step: a select right behind a load would make the wave wait for it and undo the prefetch
     auto load = [&](uint32_t t, u4 (&a)[4], u4 (&b)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t off = t * 128u + h * 64u + (uint32_t)q * 16u;
-            const bool in = off < pitch;                          // rows are zero padded to the pitch; past it the lane contributes zeros
-            const uint32_t o = in ? off : 0u;
-            u4 va = *(const u4 *)(pa + o), vb = *(const u4 *)(pb + o);
-            if (!in) { va = u4{0u, 0u, 0u, 0u}; vb = u4{0u, 0u, 0u, 0u}; }
-            a[q] = va; b[q] = vb;
+            const uint32_t o = off < pitch ? off : 0u;
+            a[q] = *(const u4 *)(pa + o); b[q] = *(const u4 *)(pb + o);
         }
     };
-    u4 a0[4], b0[4], a1[4], b1[4];
+    auto mma = [&](uint32_t t, u4 (&a)[4], u4 (&b)[4]) {
+        if (t >= nfull) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (t * 128u + h * 64u + (uint32_t)q * 16u >= pitch) { a[q] = u4{0u, 0u, 0u, 0u}; b[q] = u4{0u, 0u, 0u, 0u}; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a[q]), __builtin_bit_cast(half8, b[q]), acc, 0, 0, 0);
+    };
+    // three register sets: two super-steps of loads in flight behind the one being multiplied
+    u4 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
     load(0u, a0, b0);
-    for (uint32_t t = 0; t < nsteps; t += 2u) {
-        if (t + 1u < nsteps) load(t + 1u, a1, b1);
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a0[q]), __builtin_bit_cast(half8, b0[q]), acc, 0, 0, 0);
+    if (nsteps > 1u) load(1u, a1, b1);
+    for (uint32_t t = 0; t < nsteps; t += 3u) {
+        if (t + 2u < nsteps) load(t + 2u, a2, b2);
+        mma(t, a0, b0);
         if (t + 1u < nsteps) {
-            if (t + 2u < nsteps) load(t + 2u, a0, b0);
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a1[q]), __builtin_bit_cast(half8, b1[q]), acc, 0, 0, 0);
+            if (t + 3u < nsteps) load(t + 3u, a0, b0);
+            mma(t + 1u, a1, b1);
+        }
+        if (t + 2u < nsteps) {
+            if (t + 4u < nsteps) load(t + 4u, a1, b1);
+            mma(t + 2u, a2, b2);
         }
     }
     // C/D layout of the 32x32 forms: column = lane & 31 (B row), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (A row)
