@@ -483,7 +483,7 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
 }
 
 template <class OP, int MODE, int LPR>
-__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : FUSED_MINW))
+__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : MODE == 1 ? FUSED_MINW_INS : FUSED_MINW))
 k_fused(const FusedParams p_in)
 {
     FusedParams p = p_in;

@@ -35,7 +35,8 @@ __global__ void k_groups(const unsigned long long *keys, const uint32_t *flag, c
 }
 
 // launch order: lists with a long chain of ops (>= hub_min) for k_links_hub, the others for k_links_cached; counters[1] = hubs, [2] = others, [3] = longest chain
-__global__ void k_split(const uint32_t *off, const uint32_t *counters_in, uint32_t hub_min, uint32_t *gmap_hub, uint32_t *gmap_norm, uint32_t *counters)
+__global__ void k_split(const uint32_t *off, const uint32_t *counters_in, uint32_t hub_min, uint32_t *gmap_hub, uint32_t *gmap_norm, uint32_t *counters,
+                        const uint32_t *tg, const uint32_t *ly, const uint16_t *l0_cnt, const uint8_t *pm_valid, uint32_t lm0, uint32_t *gmap_fill)
 {   // one atomic per wave and class (every thread hitting the same three counters serialises: measured 1.2 ms per batch)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     const bool in = g < counters_in[0];
@@ -47,6 +48,16 @@ __global__ void k_split(const uint32_t *off, const uint32_t *counters_in, uint32
     bh = __shfl(bh, 0, 64); bn = __shfl(bn, 0, 64);
     if (hub) gmap_hub[bh + (uint32_t)__popcll(mh & below)] = g;
     if (norm) gmap_norm[bn + (uint32_t)__popcll(mn & below)] = g;
+    // full layer-0 lists whose resident pair matrix is missing: k_pm_fill computes it before the back-link kernels run (counters[4])
+    if (pm_valid) {
+        bool fill = false;
+        if (in && ly[g] == 0u) { const uint32_t t = tg[g]; fill = l0_cnt[t] == lm0 && pm_valid[t] < lm0; }
+        const unsigned long long mf = __ballot(fill);
+        uint32_t bf = 0;
+        if (lane == 0 && mf) bf = atomicAdd(&counters[4], (uint32_t)__popcll(mf));
+        bf = __shfl(bf, 0, 64);
+        if (fill) gmap_fill[bf + (uint32_t)__popcll(mf & below)] = g;
+    }
     uint32_t mx = c;
     for (int o = 32; o >= 1; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)mx, o, 64); mx = other > mx ? other : mx; }
     if (lane == 0 && mx) atomicMax(&counters[3], mx);
@@ -73,7 +84,7 @@ int hx_group_stage(hx_engine *e, uint32_t n_ops, HxGroupWork &w, unsigned long l
 // Device arrays of HxGroupWork are (re)allocated here for n_ops ops; afterwards w.d_keys / w.d_new / w.d_d are where the ops
 // (op order) must be put -- uploaded by hx_group_ops, or written in place by the batch pipeline's emission kernel (hx_batch.hip).
 namespace {
-struct GroupLayout { size_t kin, kout, iin, iout, nin, din, ns, ds, flag, gid, tg, ly, off, gh, gn, ctr, tmp, total, tmp_bytes; };
+struct GroupLayout { size_t kin, kout, iin, iout, nin, din, ns, ds, flag, gid, tg, ly, off, gh, gn, gf, ctr, tmp, total, tmp_bytes; };
 int group_layout(hx_engine *e, uint32_t n_ops, GroupLayout &L)
 {
     hipStream_t st = e->stream;
@@ -91,7 +102,7 @@ int group_layout(hx_engine *e, uint32_t n_ops, GroupLayout &L)
     L.ns = o; o += al(n * 4); L.ds = o; o += al(n * 4);
     L.flag = o; o += al(n * 4); L.gid = o; o += al(n * 4);
     L.tg = o; o += al(n * 4); L.ly = o; o += al(n * 4); L.off = o; o += al((n + 1) * 4);
-    L.gh = o; o += al(n * 4); L.gn = o; o += al(n * 4);
+    L.gh = o; o += al(n * 4); L.gn = o; o += al(n * 4); L.gf = o; o += al(n * 4);
     L.ctr = o; o += 256;
     L.tmp = o; o += al(L.tmp_bytes);
     L.total = o;
@@ -116,9 +127,10 @@ int hx_group_reserve(hx_engine *e, uint32_t n_ops, HxGroupWork &w)
 }
 
 // groups the n_ops ops already present in w.d_keys / w.d_new / w.d_d (hx_group_reserve(n_ops) placed those arrays)
-int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w, uint32_t counters_out[4])
+int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w, uint32_t counters_out[5], bool want_fill)
 {
-    if (n_ops == 0) { counters_out[0] = counters_out[1] = counters_out[2] = counters_out[3] = 0; return HX_OK; }
+    for (int i = 0; i < 5; i++) counters_out[i] = 0;
+    if (n_ops == 0) return HX_OK;
     HX_HIP(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
     GroupLayout L; int rc = group_layout(e, n_ops, L); if (rc) return rc;
@@ -137,11 +149,14 @@ int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w,
     hipLaunchKernelGGL(k_groups, dim3(gb), dim3(tb), 0, st, (const unsigned long long *)(b + L.kout), (const uint32_t *)(b + L.flag), (const uint32_t *)(b + L.gid),
                        (uint32_t *)(b + L.tg), (uint32_t *)(b + L.ly), (uint32_t *)(b + L.off), n_ops, (uint32_t *)(b + L.ctr));
     hipLaunchKernelGGL(k_split, dim3(gb), dim3(tb), 0, st, (const uint32_t *)(b + L.off), (const uint32_t *)(b + L.ctr), hub_min,
-                       (uint32_t *)(b + L.gh), (uint32_t *)(b + L.gn), (uint32_t *)(b + L.ctr));
+                       (uint32_t *)(b + L.gh), (uint32_t *)(b + L.gn), (uint32_t *)(b + L.ctr),
+                       (const uint32_t *)(b + L.tg), (const uint32_t *)(b + L.ly), (const uint16_t *)e->mirror.d_l0_cnt, want_fill ? (const uint8_t *)e->mirror.d_pm_valid : nullptr, 2u * e->mirror.m,
+                       (uint32_t *)(b + L.gf));
     HX_HIP(e, hipGetLastError());
-    HX_HIP(e, hipMemcpyAsync(w.h_ctr, b + L.ctr, 16, hipMemcpyDeviceToHost, st));
+    HX_HIP(e, hipMemcpyAsync(w.h_ctr, b + L.ctr, 20, hipMemcpyDeviceToHost, st));
     HX_HIP(e, hipStreamSynchronize(st));
-    for (int i = 0; i < 4; i++) counters_out[i] = w.h_ctr[i];
+    for (int i = 0; i < 5; i++) counters_out[i] = w.h_ctr[i];
+    w.gmap_fill = (const uint32_t *)(b + L.gf);
     w.tg = (const uint32_t *)(b + L.tg); w.ly = (const uint32_t *)(b + L.ly); w.off = (const uint32_t *)(b + L.off);
     w.op_new = (const uint32_t *)(b + L.ns); w.op_d = (const float *)(b + L.ds);
     w.gmap_hub = (const uint32_t *)(b + L.gh); w.gmap_norm = (const uint32_t *)(b + L.gn);
@@ -150,12 +165,13 @@ int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w,
 
 // keys / new ids / distances arrive in host memory (op order)
 int hx_group_ops(hx_engine *e, uint32_t n_ops, const unsigned long long *h_keys, const uint32_t *h_new, const float *h_d, uint32_t hub_min,
-                 HxGroupWork &w, uint32_t counters_out[4])
+                 HxGroupWork &w, uint32_t counters_out[5], bool want_fill)
 {
-    if (n_ops == 0) { counters_out[0] = counters_out[1] = counters_out[2] = counters_out[3] = 0; return HX_OK; }
+    for (int i = 0; i < 5; i++) counters_out[i] = 0;
+    if (n_ops == 0) return HX_OK;
     int rc = hx_group_reserve(e, n_ops, w); if (rc) return rc;
     HX_HIP(e, hipMemcpyAsync(w.d_keys, h_keys, (size_t)n_ops * 8, hipMemcpyHostToDevice, e->stream));
     HX_HIP(e, hipMemcpyAsync(w.d_new, h_new, (size_t)n_ops * 4, hipMemcpyHostToDevice, e->stream));
     HX_HIP(e, hipMemcpyAsync(w.d_d, h_d, (size_t)n_ops * 4, hipMemcpyHostToDevice, e->stream));
-    return hx_group_run(e, n_ops, hub_min, w, counters_out);
+    return hx_group_run(e, n_ops, hub_min, w, counters_out, want_fill);
 }

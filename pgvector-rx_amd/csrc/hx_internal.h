@@ -65,7 +65,7 @@ struct HxFusedDev { uint32_t *d_rec = nullptr; uint32_t rec_words = 0; const uin
 // device-side grouping of a batch's back-link ops (hx_group.hip): workspace + the grouped arrays it leaves on the device
 struct HxGroupWork {
     uint8_t *d = nullptr; size_t cap = 0; uint32_t *h_ctr = nullptr; uint8_t *h = nullptr; size_t cap_h = 0;   // device workspace, pinned counters, pinned op staging
-    const uint32_t *tg = nullptr, *ly = nullptr, *off = nullptr, *op_new = nullptr, *gmap_hub = nullptr, *gmap_norm = nullptr; const float *op_d = nullptr;
+    const uint32_t *tg = nullptr, *ly = nullptr, *off = nullptr, *op_new = nullptr, *gmap_hub = nullptr, *gmap_norm = nullptr, *gmap_fill = nullptr; const float *op_d = nullptr;
     unsigned long long *d_keys = nullptr; uint32_t *d_new = nullptr; float *d_d = nullptr;   // where the ungrouped ops go (after hx_group_reserve)
 };
 // workspace of the device-resident batch pipeline (hx_batch.hip)
@@ -81,9 +81,9 @@ struct hx_engine;
 static inline uint32_t hx_xrec_words(uint32_t m) { return (3u + 4u * m + 3u) & ~3u; }   // list record of the multi-GPU exchange: target, layer, cnt, ids[2m], d[2m]
 int hx_group_stage(hx_engine *e, uint32_t n_ops, HxGroupWork &w, unsigned long long **keys, uint32_t **op_new, float **op_d);
 int hx_group_reserve(hx_engine *e, uint32_t n_ops, HxGroupWork &w);
-int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w, uint32_t counters_out[4]);
+int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w, uint32_t counters_out[5], bool want_fill = false);   // counters: groups, hub lists, other lists, longest chain, lists whose pair matrix k_pm_fill must compute
 int hx_group_ops(hx_engine *e, uint32_t n_ops, const unsigned long long *h_keys, const uint32_t *h_new, const float *h_d, uint32_t hub_min,
-                 HxGroupWork &w, uint32_t counters_out[4]);   // counters: groups, hub lists, other lists, longest chain
+                 HxGroupWork &w, uint32_t counters_out[5], bool want_fill = false);
 
 // arguments of an iterative scan on the device (k_fused MODE 2)
 struct HxFusedIter {

@@ -223,8 +223,9 @@ k_pm_fill(const LinksParams p, float *pm, uint8_t *pm_valid)
     uint8_t *bufs = lds;
     uint32_t *lid = (uint32_t *)(lds + 2 * buf_bytes);           // list ids [40]
     float *tri = (float *)(lid + 40);                            // packed lower triangle [528]
-    const uint32_t g = blockIdx.x;
-    if (g >= p.n_groups || p.layer[g] != 0u) return;
+    if (blockIdx.x >= p.n_groups) return;
+    const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
+    if (p.layer[g] != 0u) return;
     const uint32_t target = p.target[g], lm = 2u * p.m;
     const uint32_t cnt = p.l0_cnt[target];
     if (cnt != lm || pm_valid[target] >= cnt) return;            // not full yet (appends come first), or already cached
@@ -773,8 +774,9 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
         mr.cap_lk = 4096;
     }
     static const uint32_t hub_min = getenv("HX_HUB_MIN") ? (uint32_t)atoi(getenv("HX_HUB_MIN")) : 48u;
-    uint32_t c[4];
-    int rc = on_device ? hx_group_run(this, n_ops, hub_min, grp, c) : hx_group_ops(this, n_ops, keys, op_new, op_d, hub_min, grp, c);
+    static const bool prefill = !(getenv("HX_PM_PREFILL") && atoi(getenv("HX_PM_PREFILL")) == 0);
+    uint32_t c[5];
+    int rc = on_device ? hx_group_run(this, n_ops, hub_min, grp, c, use_pm && prefill) : hx_group_ops(this, n_ops, keys, op_new, op_d, hub_min, grp, c, use_pm && prefill);
     if (rc) return rc;
     const uint32_t n_groups = c[0], n_hub = c[1], n_norm = c[2];
     stats[0] = n_groups; stats[1] = c[3];
@@ -804,11 +806,11 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
     float *pm_save = mr.d_pm;
-    static const bool prefill = !(getenv("HX_PM_PREFILL") && atoi(getenv("HX_PM_PREFILL")) == 0);
-    if (use_pm && prefill) {                                     // pair matrices of the full lists that are pruned for the first time
-#define F32C(K) ls = launch_pm_fill<OpF32<K>>(this, p)
-#define F16C(K) ls = launch_pm_fill<OpF16<K>>(this, p)
-        HX_DISPATCH(this, F32C, F16C, ls = launch_pm_fill<OpHamming>(this, p), ls = launch_pm_fill<OpJaccard>(this, p));
+    if (use_pm && prefill && c[4]) {                             // pair matrices of the full lists that are pruned for the first time (compacted by k_split)
+        LinksParams pf = p; pf.n_groups = c[4]; pf.gmap = grp.gmap_fill;
+#define F32C(K) ls = launch_pm_fill<OpF32<K>>(this, pf)
+#define F16C(K) ls = launch_pm_fill<OpF16<K>>(this, pf)
+        HX_DISPATCH(this, F32C, F16C, ls = launch_pm_fill<OpHamming>(this, pf), ls = launch_pm_fill<OpJaccard>(this, pf));
 #undef F32C
 #undef F16C
         HX_HIP(this, ls);
