@@ -144,6 +144,17 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)
+    # stdout carries ONE line, the JSON: libraries that print to fd 1 (gloo's "[Gloo] Rank 0 is connected ..." banner) go to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        run(a, json_fd)
+    finally:
+        os.close(json_fd)
+
+
+def run(a, json_fd):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -333,9 +344,18 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                if rec.get("rows") == a.rows and rec.get("dim") == a.dim and rec.get("queries") == a.queries and rec.get("efs") == a.efs:
+                import glob
+                import hashlib
+                hh = hashlib.sha256()
+                for f in sorted(glob.glob(os.path.join(ROOT, "pgvector-rx_amd", "csrc", "*"))):
+                    hh.update(os.path.basename(f).encode())
+                    hh.update(open(f, "rb").read())
+                same_kernels = rec.get("csrc_sha16") == hh.hexdigest()[:16]
+                if rec.get("rows") == a.rows and rec.get("dim") == a.dim and rec.get("queries") == a.queries and rec.get("efs") == a.efs and same_kernels:
                     roofline["traffic"] = rec["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = rec.get("source")
+                elif not same_kernels:
+                    roofline["traffic_source"] = "none: the kernel sources changed since the recorded rocprofv3 --pmc FETCH_SIZE pass (profiles/pmc_k_fused_query.json)"
             except Exception:
                 pass
     bd, bp = build_stats["dist"], build_stats["pair"]
@@ -446,7 +466,7 @@ def main():
         "dist_build_stage_seconds_rank0": dist_stages,
         "build_distance_evals": {"search": int(counters[1]), "select": int(counters[2]), "backlink": int(counters[3])},
     }
-    print(json.dumps(out), flush=True)
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
