@@ -462,6 +462,9 @@ def run(a, json_fd):
         "build_kernels": build_kernels,
         "host_profile": {"build": {k: round(v, 2) for k, v in build_prof.items()}, "search_all_steps": {k: round(v, 3) for k, v in search_prof.items()}},
         "fused": ix.fused_stats(),
+        "parity": "graphs, top-k lists and iterative scans bit-identical to the CPU oracle run in the device's canonical summation order (ORC_ORDER_W64: tests/, -m gpu); "
+                  "distances within 1e-5 * d (L2, L1) / 1e-5 * sum|a_i b_i| (inner product) of the reference's sequential f32 order; the build uses snapshot batches "
+                  "(insert_batch_cap), whose recall equals the reference's one-row-at-a-time schedule query by query at 100k x 768 (tests/test_gpu_recall_parity.py)",
         "dist_backend": (comm.backend if comm is not None else None),
         "dist_build_stage_seconds_rank0": dist_stages,
         "build_distance_evals": {"search": int(counters[1]), "select": int(counters[2]), "backlink": int(counters[3])},

@@ -1,20 +1,23 @@
-// hx_fused.inc.h -- included by hx_engine.hip.  Device-resident HNSW traversal: one wavefront per search.
+// hx_fused.inc.h -- included by hx_engine.hip: the host side of the device-resident traversal (graph mirror maintenance, fused_run).
 //
-// The lock-step host driver (hx_index.cpp) pays one host round trip per candidate expansion.  This file moves the
-// whole of search_layer (graph/mod.rs:161-255 / scan.rs:302-448), the greedy descent and per-layer loop of
-// find_element_neighbors (graph/mod.rs:355-427) / get_scan_items (scan.rs:458-530) and select_neighbors
-// (graph/mod.rs:269-339) into ONE persistent kernel:
-//   * a 64-thread workgroup (one wavefront) owns one insert or query from start to finish; workgroups pull tasks
-//     from an atomic counter until none are left (every wave reaches the exit: the counter only grows);
-//   * the candidate heap C, the result heap W, the entry-point / sorted-candidate array and the select lists live
-//     in LDS; the heaps use the same Rust-std sift order as the host driver and the oracle, executed by lane 0;
-//   * the query's 16-byte fragments stay in registers; an expansion reads the candidate's neighbour ids (coalesced),
-//     test-and-sets a per-workgroup visited bitmap with L2 atomics, and evaluates the unvisited rows with the SAME
-//     canonical summation order as K1/K2 (lane l owns bytes chunk*1024+16*l, xor butterfly), 4 rows in flight;
-//   * the graph is read from a device mirror (ids only) that the host refreshes after each batch.
-// Results (neighbour lists with distances / top-k) are therefore bit-identical to the lock-step path; the
-// tests compare the two paths and the oracle.  A task whose candidate heap would overflow its LDS budget reports
-// FS_OVERFLOW and is re-run by the lock-step path (still on the GPU kernels: there is no CPU fallback).
+// The lock-step host driver (hx_index.cpp) pays one host round trip per candidate expansion.  The traversal kernel
+// (hx_fused_kernel.h, compiled per element type in hx_fused_{f32,f16,bit}.hip) moves the whole of search_layer
+// (graph/mod.rs:161-255 / scan.rs:302-448), the greedy descent and per-layer loop of find_element_neighbors (graph/mod.rs:355-427) /
+// get_scan_items (scan.rs:458-530), the iterative-scan loop (scan.rs:794-875) and select_neighbors (graph/mod.rs:269-339) into ONE
+// persistent kernel:
+//   * one wavefront owns one insert or query from start to finish; waves pull tasks from an atomic counter until none are left
+//     (every wave reaches the exit: the counter only grows);
+//   * the candidate heap C (LDS head, tail spilled to a per-wave area in global memory), the result heap W, the entry-point /
+//     sorted-candidate array and the select lists live in LDS; both heaps are driven by the WHOLE wave (PHeap: ancestor gather + ballot +
+//     scatter) to the array states Rust's BinaryHeap produces, as the host driver and the oracle do;
+//   * the query is parked in LDS; an expansion reads the candidate's neighbour ids (coalesced), tests them against a per-wave visited
+//     hash table in global memory (16-byte buckets, one L1-bypassing load per test, the insert's CAS settled after the row loads) and
+//     evaluates the unvisited rows in the canonical summation order of K1/K2 (lane l owns bytes chunk*1024+16*l, xor butterfly),
+//     4 rows x 3 chunks in flight, loads issued unconditionally from scalar row bases;
+//   * the graph is read from the device mirror, which during a build is the authoritative copy (hx_batch.hip).
+// Results (neighbour lists with distances / top-k) are bit-identical to the lock-step path; the tests compare the two paths and the oracle.
+// A task whose tables overflow reports FS_OVERFLOW, is retried once on the device with 8x the tables and only then re-run by the lock-step
+// path (still on the GPU kernels: there is no CPU fallback).
 
 #include "hx_fused_core.h"
 

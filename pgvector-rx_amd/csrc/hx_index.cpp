@@ -1386,7 +1386,7 @@ int hx_index_batch_import_links(hx_index *ix, const void *buf, uint64_t nbytes)
     std::vector<size_t> off;                                   // record boundaries (the record size depends on its layer)
     for (size_t o = 0; o + 8 <= nbytes;) {
         uint32_t tg, ly; memcpy(&tg, base + o, 4); memcpy(&ly, base + o + 4, 4);
-        if (tg >= g.size() || g.level[tg] < (int)ly) return ix->fail(HX_E_ARG, "corrupt link record");
+        if (tg >= g.size() || g.level[tg] < 0 || ly > (uint32_t)g.level[tg]) return ix->fail(HX_E_ARG, "corrupt link record");   // unsigned: a layer word >= 2^31 must not pass as negative
         off.push_back(o);
         o += 8 + list_bytes(g, (int)ly);
         if (o > nbytes) return ix->fail(HX_E_ARG, "truncated link record");
