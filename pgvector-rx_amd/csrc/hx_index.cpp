@@ -154,6 +154,22 @@ struct Graph {
         tids.emplace_back(); ntids.push_back(0); deleted.push_back(0);
         return id;
     }
+    // b elements at once (a batch): every array grows once instead of b times
+    void add_bulk(const int32_t *levels, uint32_t b, int max_level)
+    {
+        const size_t n0sz = level.size();
+        size_t up_add = 0;
+        for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[i], max_level); if (lv < 0) lv = 0; up_add += (size_t)lv; }
+        level.resize(n0sz + b); n0_cnt.resize(n0sz + b, 0); n0.resize((n0sz + b) * 2 * (size_t)m);
+        up_off.resize(n0sz + b); upc_off.resize(n0sz + b); tids.resize(n0sz + b); ntids.resize(n0sz + b, 0); deleted.resize(n0sz + b, 0);
+        size_t uo = up.size(), co = up_cnt.size();
+        up.resize(uo + up_add * (size_t)m); up_cnt.resize(co + up_add, 0);
+        for (uint32_t i = 0; i < b; i++) {
+            int lv = std::min(levels[i], max_level); if (lv < 0) lv = 0;
+            level[n0sz + i] = lv; up_off[n0sz + i] = uo; upc_off[n0sz + i] = co;
+            uo += (size_t)lv * m; co += (size_t)lv;
+        }
+    }
     Cand *list(uint32_t e, int layer) { return layer == 0 ? &n0[(size_t)e * 2 * m] : &up[up_off[e] + (size_t)(layer - 1) * m]; }
     const Cand *list(uint32_t e, int layer) const { return const_cast<Graph *>(this)->list(e, layer); }
     uint16_t &cnt(uint32_t e, int layer) { return layer == 0 ? n0_cnt[e] : up_cnt[upc_off[e] + (layer - 1)]; }
@@ -773,7 +789,7 @@ struct hx_index {
 
     bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192; }
     // device-resident batches (hx_batch.hip): the traversal kernel and the back-link kernels both serve this m
-    bool dbatch_ok() const { static const bool off = getenv("HX_DEVICE_BATCH") && atoi(getenv("HX_DEVICE_BATCH")) == 0; return !off && fused_ok() && 2 * g.m <= 32; }
+    bool dbatch_ok() const { static const bool off = getenv("HX_DEVICE_BATCH") && atoi(getenv("HX_DEVICE_BATCH")) == 0; return !off && fused_ok() && 2 * g.m <= 64; }
     void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
     // brings the device copy of the graph up to date: levels of new elements + every list written since the last sync
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -1040,7 +1056,7 @@ int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int
     }
     bs.open = true; bs.base = g.size(); bs.b = b; bs.entry = (uint32_t)g.entry; bs.entry_level = g.level[g.entry];
     bs.tids.assign(tids, tids + b); bs.elem.assign(b, 0); bs.searched.assign(b, 0);
-    for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[i], mxl); if (lv < 0) lv = 0; g.add(lv); }
+    g.add_bulk(levels, b, mxl);
     return HX_OK;
 }
 
@@ -1449,7 +1465,7 @@ int hx_index_dbatch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const in
     }
     bs.open = true; bs.dev = true; bs.base = g.size(); bs.b = b; bs.entry = (uint32_t)g.entry; bs.entry_level = g.level[g.entry];
     bs.tids.assign(tids, tids + b); bs.elem.assign(b, 0); bs.searched.assign(b, 0);
-    for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[i], mxl); if (lv < 0) lv = 0; g.add(lv); }
+    g.add_bulk(levels, b, mxl);
     // levels / upper-layer blocks of the new elements and every list the host wrote since the last launch go to the mirror now;
     // from here on the mirror is the only place this batch's lists exist
     int rc = ix->sync_mirror();

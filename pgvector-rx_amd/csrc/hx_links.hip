@@ -246,7 +246,7 @@ k_pm_fill(const LinksParams p, float *pm, uint8_t *pm_valid)
 // SPEC == false: applies the op; returns true when the list was pruned (it is then in select order, its matrix complete).
 // SPEC == true: touches only the scratch arrays and answers "would this op change the list?" -- false only when it is certain
 // that the new row is the one left out and every survivor keeps its slot (then list, distances and matrix stay as they are).
-template <class OP, int LPR, bool SPEC>
+template <class OP, int LPR, bool SPEC, int SLOTS = LC_SLOTS>   // SLOTS: list capacity the kernel is built for (32: m <= 16, 64: m <= 32); also the index that stands for the new row
 __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
                       float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, uint8_t *QV,
                       uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist, unsigned long long *tk = nullptr,
@@ -281,14 +281,17 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
         // the slots already accepted when the walk reaches the new row first (FUSED_RB at a time, stop at the first batch
         // with a hit, like check_element_closer's early return), the remaining slots only if the new row stays in the list.
         const uint32_t n = cnt + 1;                                                // mod.rs:474-482: items + new, stable sort by distance
-        {   // rank sort: every lane compares its distance with lane j's, read through the scalar unit (no LDS traffic)
-            const float d = lane < cnt ? ld[lane] : new_d; uint32_t rank = 0;
+        {   // stable rank sort of list + new row (the new row is the LAST candidate, so equal distances keep list entries first): every lane
+            // compares its distance with lane j's, read through the scalar unit (no LDS traffic); the new row has no lane of its own when cnt = 64
+            const float d = lane < cnt ? ld[lane] : 0.0f; uint32_t rank = 0;
             const unsigned int dbits = __builtin_bit_cast(unsigned int, d);
-            for (uint32_t j = 0; j < n; j++) {
+            for (uint32_t j = 0; j < cnt; j++) {
                 const float dj = __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_readlane((int)dbits, (int)j));
                 rank += (dj < d) || (dj == d && j < lane);
             }
-            if (lane < n) { pos[rank] = lane < cnt ? lane : LC_SLOTS; sd[rank] = d; }
+            if (lane < cnt) { rank += new_d < d ? 1u : 0u; pos[rank] = lane; sd[rank] = d; }
+            const uint32_t rank_new = (uint32_t)__popcll(__ballot(lane < cnt && !(new_d < d)));      // list entries with d <= new_d go first
+            if (lane == 0) { pos[rank_new] = SLOTS; sd[rank_new] = new_d; }
         }
         F_WSYNC();
         LC_TICK(1);                                                                // sort
@@ -301,7 +304,7 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
             known = __ballot(f);
             F_WSYNC();
         }
-        const unsigned long long cmask = (1ull << cnt) - 1ull;                      // cnt <= 32
+        const unsigned long long cmask = cnt >= 64u ? ~0ull : (1ull << cnt) - 1ull;
         const uint32_t n_unk = (uint32_t)__popcll(~known & cmask);
         // select_neighbors(candidates, lm): mod.rs:284-305.  D(k1,k2) = cached pair or the new row's distance
         uint32_t r = 0, ndc = 0, n_done = 0;      // n_done: how many entries of the evaluation order ORD have their nd[]
@@ -329,7 +332,7 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
             if (r >= lm) break;
             const float ed = sd[i]; const uint32_t si = pos[i];
             bool closer;
-            if (si == LC_SLOTS) {
+            if (si == SLOTS) {
                 LC_TICK(2);                                                        // walk so far
                 // accepted slots decide (mod.rs:324-336): first the ones whose distance is already known, then the rest streamed
                 // FUSED_RB at a time, stopping at the first batch with a hit like check_element_closer's early return
@@ -355,7 +358,7 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
                 bool hit = false;
                 if (lane < r) {
                     const uint32_t sj = my_slot;                                   // slot of the lane-th accepted candidate (== pos[sel[lane]])
-                    const float dij = sj == LC_SLOTS ? nd[si] : M[lc_tri(si, sj)];
+                    const float dij = sj == SLOTS ? nd[si] : M[lc_tri(si, sj)];
                     hit = dij <= ed;                                               // mod.rs:333-335
                 }
                 closer = __ballot(hit) == 0ull;
@@ -377,15 +380,15 @@ __device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, flo
             if (!changed) { LC_TICK(4); return true; }            // (a pruned list stays in select order: still "pruned" for the caller)
         }
         {   // the new row's distances to every slot are needed only if it stays in the list
-            bool mine = lane < r && pos[sel[lane]] == LC_SLOTS;
+            bool mine = lane < r && pos[sel[lane]] == SLOTS;
             if (__ballot(mine) != 0ull) finish_nd();
         }
         // surviving list and its pair matrix
-        if (lane < r) { const uint32_t sa = pos[sel[lane]]; lid2[lane] = sa == LC_SLOTS ? new_id : lid[sa]; ld2[lane] = sd[sel[lane]]; }
+        if (lane < r) { const uint32_t sa = pos[sel[lane]]; lid2[lane] = sa == SLOTS ? new_id : lid[sa]; ld2[lane] = sd[sel[lane]]; }
         for (uint32_t idx = lane; idx < r * (r - 1) / 2; idx += 64) {
             uint32_t a, b; tri_decode(idx, a, b);
             const uint32_t sa = pos[sel[a]], sb = pos[sel[b]];
-            M2[idx] = sa == LC_SLOTS ? nd[sb] : (sb == LC_SLOTS ? nd[sa] : M[lc_tri(sa, sb)]);
+            M2[idx] = sa == SLOTS ? nd[sb] : (sb == SLOTS ? nd[sa] : M[lc_tri(sa, sb)]);
         }
         F_WSYNC();
         if (lane < r) { lid[lane] = lid2[lane]; ld[lane] = ld2[lane]; }
@@ -406,20 +409,21 @@ __device__ __forceinline__ const uint2 *lk_wtab(const LinksParams &p, uint32_t l
     return p.wtab + (size_t)k * p.wt_size;
 }
 
-template <class OP, int LPR>
+template <class OP, int LPR, int SLOTS>
 __global__ void __launch_bounds__(64, 4)
 k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
 {
+    constexpr int AR = SLOTS + 8, MT = (SLOTS + 1) * SLOTS / 2;      // list-sized arrays; packed lower triangle over SLOTS + 1 candidates
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float *M = (float *)lds;                       // pair matrix over list slots, packed lower triangle [528]
-    float *M2 = M + 528;
-    uint32_t *lid = (uint32_t *)(M2 + 528);        // list ids / distances to the target [40]
-    float *ld = (float *)(lid + 40);
-    uint32_t *lid2 = (uint32_t *)(ld + 40); float *ld2 = (float *)(lid2 + 40);
-    float *nd = ld2 + 40;                          // d(new row, slot j)
-    uint32_t *pos = (uint32_t *)(nd + 40);         // sorted candidate k -> slot (LC_SLOTS = the new row)
-    float *sd = (float *)(pos + 40);
-    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *ORD = dis + 40, *IDS = ORD + 40;   // IDS[64]
+    float *M2 = M + MT;
+    uint32_t *lid = (uint32_t *)(M2 + MT);        // list ids / distances to the target [40]
+    float *ld = (float *)(lid + AR);
+    uint32_t *lid2 = (uint32_t *)(ld + AR); float *ld2 = (float *)(lid2 + AR);
+    float *nd = ld2 + AR;                          // d(new row, slot j)
+    uint32_t *pos = (uint32_t *)(nd + AR);         // sorted candidate k -> slot (LC_SLOTS = the new row)
+    float *sd = (float *)(pos + AR);
+    uint32_t *sel = (uint32_t *)(sd + AR), *dis = sel + AR, *ORD = dis + AR, *IDS = ORD + AR;   // IDS[64]
     float *DSC = (float *)(IDS + 64);
     uint8_t *QV = (uint8_t *)(DSC + 64);
     const uint32_t lane = threadIdx.x;
@@ -443,7 +447,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
     const bool tm = (p.dbg & 8u) != 0; const unsigned long long tk0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++)
-        (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr,
+        (void)lc_op<OP, LPR, false, SLOTS>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr,
                                     lk_wtab(p, layer, p.op_new[op]), p.wt_size - 1u);
     if (lane < cnt) {
         gl_ids[lane] = lid[lane]; gl_d[lane] = ld[lane];
@@ -474,21 +478,22 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
 #ifndef HUB_W
 #define HUB_W 8
 #endif
-template <class OP, int LPR>
+template <class OP, int LPR, int SLOTS>
 __global__ void __launch_bounds__(64 * HUB_W, 1)
 k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
 {
+    constexpr int AR = SLOTS + 8, MT = (SLOTS + 1) * SLOTS / 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t nchb = ((p.pitch + 1023u) / 1024u) * 1024u;
     // shared: M[528] M2[528] lid[40] ld[40] lid2[40] ld2[40] ctl[16]; per wave: nd pos sd sel dis ORD [40 each] IDS[64] DSC[64] QV[nchb]
-    float *M = (float *)lds, *M2 = M + 528;
-    uint32_t *lid = (uint32_t *)(M2 + 528); float *ld = (float *)(lid + 40);
-    uint32_t *lid2 = (uint32_t *)(ld + 40); float *ld2 = (float *)(lid2 + 40);
-    uint32_t *ctl = (uint32_t *)(ld2 + 40);
-    uint8_t *wbase = (uint8_t *)(ctl + 16) + (size_t)wave * ((40 * 6 + 64 + 64) * 4 + nchb);
-    float *nd = (float *)wbase; uint32_t *pos = (uint32_t *)(nd + 40); float *sd = (float *)(pos + 40);
-    uint32_t *sel = (uint32_t *)(sd + 40), *dis = sel + 40, *ORD = dis + 40, *IDS = ORD + 40;
+    float *M = (float *)lds, *M2 = M + MT;
+    uint32_t *lid = (uint32_t *)(M2 + MT); float *ld = (float *)(lid + AR);
+    uint32_t *lid2 = (uint32_t *)(ld + AR); float *ld2 = (float *)(lid2 + AR);
+    uint32_t *ctl = (uint32_t *)(ld2 + AR);
+    uint8_t *wbase = (uint8_t *)(ctl + 16) + (size_t)wave * ((AR * 6 + 64 + 64) * 4 + nchb);
+    float *nd = (float *)wbase; uint32_t *pos = (uint32_t *)(nd + AR); float *sd = (float *)(pos + AR);
+    uint32_t *sel = (uint32_t *)(sd + AR), *dis = sel + AR, *ORD = dis + AR, *IDS = ORD + AR;
     float *DSC = (float *)(IDS + 64);
     uint8_t *QV = (uint8_t *)(DSC + 64);
     if (blockIdx.x >= p.n_groups) return;
@@ -515,7 +520,7 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
         if (!canon || cnt < lm || v < cnt) {                       // appends, the first prune, missing pairs: the ordinary path, one op
             __syncthreads();
             if (wave == 0) {
-                const bool pruned = lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, nullptr,
+                const bool pruned = lc_op<OP, LPR, false, SLOTS>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, nullptr,
                                                           lk_wtab(p, layer, p.op_new[op]), p.wt_size - 1u);
                 if (lane == 0) { ctl[0] = op + 1u; ctl[1] = cnt; ctl[2] = v; if (pruned) ctl[3] = 1u; }
             }
@@ -525,7 +530,7 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
         bool changed = false;
         if (wave < nv) {
             uint32_t c2 = cnt, v2 = v;
-            changed = lc_op<OP, LPR, true>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, c2, v2, lm, p.op_new[op + wave], p.op_d[op + wave], lane, ndist, nullptr,
+            changed = lc_op<OP, LPR, true, SLOTS>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, c2, v2, lm, p.op_new[op + wave], p.op_d[op + wave], lane, ndist, nullptr,
                                            lk_wtab(p, layer, p.op_new[op + wave]), p.wt_size - 1u);
         }
         if (lane == 0) ctl[4 + wave] = changed ? 1u : 0u;
@@ -535,7 +540,7 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
         __syncthreads();
         if (first == nv) { if (threadIdx.x == 0) ctl[0] = op + nv; continue; }
         if (wave == 0) {
-            (void)lc_op<OP, LPR, false>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op + first], p.op_d[op + first], lane, ndist, nullptr,
+            (void)lc_op<OP, LPR, false, SLOTS>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op + first], p.op_d[op + first], lane, ndist, nullptr,
                                         lk_wtab(p, layer, p.op_new[op + first]), p.wt_size - 1u);
             if (lane == 0) { ctl[0] = op + first + 1u; ctl[1] = cnt; ctl[2] = v; }
         }
@@ -559,27 +564,39 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
     if (lane == 0) atomicAdd(p.n_pairs, ndist);
 }
 
+template <class OP, int LPR, int SLOTS>
+static hipError_t launch_links_cached_s(hx_engine *e, const LinksParams &p)
+{
+    constexpr size_t AR = SLOTS + 8, MT = (SLOTS + 1) * SLOTS / 2;
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (MT * 2 + AR * 11 + 64 + 64) * 4 + nch * 1024;
+    hipLaunchKernelGGL((k_links_cached<OP, LPR, SLOTS>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    return hipGetLastError();
+}
 template <class OP, int LPR>
 static hipError_t launch_links_cached_lpr(hx_engine *e, const LinksParams &p)
+{   // lists of up to 32 slots (m <= 16) or 64 (m <= 32)
+    return 2 * p.m <= 32 ? launch_links_cached_s<OP, LPR, 32>(e, p) : launch_links_cached_s<OP, LPR, 64>(e, p);
+}
+template <class OP, int LPR, int SLOTS>
+static hipError_t launch_links_hub_s(hx_engine *e, const LinksParams &p)
 {
+    constexpr size_t AR = SLOTS + 8, MT = (SLOTS + 1) * SLOTS / 2;
     const size_t nch = (e->pitch + 1023) / 1024;
-    const size_t lds = (528 * 2 + 40 * 11 + 64 + 64) * 4 + nch * 1024;
-    hipLaunchKernelGGL((k_links_cached<OP, LPR>), dim3(p.n_groups), dim3(64), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
+    const size_t lds = (MT * 2 + AR * 4 + 16) * 4 + (size_t)HUB_W * ((AR * 6 + 64 + 64) * 4 + nch * 1024);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t st = hipFuncSetAttribute((const void *)k_links_hub<OP, LPR, SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (st != hipSuccess) return st;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_links_hub<OP, LPR, SLOTS>), dim3(p.n_groups), dim3(64 * HUB_W), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
     return hipGetLastError();
 }
 template <class OP, int LPR>
 static hipError_t launch_links_hub_lpr(hx_engine *e, const LinksParams &p)
 {
-    const size_t nch = (e->pitch + 1023) / 1024;
-    const size_t lds = (528 * 2 + 40 * 4 + 16) * 4 + (size_t)HUB_W * ((40 * 6 + 64 + 64) * 4 + nch * 1024);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        hipError_t st = hipFuncSetAttribute((const void *)k_links_hub<OP, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        if (st != hipSuccess) return st;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_links_hub<OP, LPR>), dim3(p.n_groups), dim3(64 * HUB_W), lds, e->stream, p, e->mirror.d_pm, e->mirror.d_pm_valid);
-    return hipGetLastError();
+    return 2 * p.m <= 32 ? launch_links_hub_s<OP, LPR, 32>(e, p) : launch_links_hub_s<OP, LPR, 64>(e, p);
 }
 template <class OP>
 static hipError_t launch_links_hub(hx_engine *e, const LinksParams &p)
@@ -748,7 +765,7 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
     if (n_pairs) *n_pairs = 0;
     xl_records = 0;
     if (n_ops == 0) return HX_OK;
-    if (2 * mr.m > LC_SLOTS || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "device-side op grouping serves m <= 16 and rows <= 8 KiB");
+    if (2 * mr.m > 64 || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "device-side op grouping serves m <= 32 and rows <= 8 KiB");
     HX_HIP(this, hipSetDevice(device));
     const bool use_pm = 2 * mr.m == LC_SLOTS;                     // the resident pair-matrix cache is laid out for 32-slot lists
     if (use_pm && mr.cap_pm < mr.cap) {                           // pair-matrix cache for every layer-0 list (as in links_run)

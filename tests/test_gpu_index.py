@@ -663,3 +663,25 @@ def test_overflowed_tasks_are_retried_on_the_device_with_roomier_tables():
         del os.environ["HX_FORCE_OVERFLOW_MOD"]
     ix.close()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,metric,dim,n,m,efc,batch", [(hx.F32, hx.L2SQ, 8, 1500, 20, 48, 64), (hx.F32, hx.NEG_IP, 12, 1200, 32, 64, 100), (hx.BIT, hx.HAMMING, 96, 1000, 24, 64, 37)])
+def test_m_above_16_stays_on_the_device(dtype, metric, dim, n, m, efc, batch):
+    """m in 17..32 (lists of up to 64): traversal, back-link kernels (64-slot build) and the batch pipeline all run on the device -- nothing falls
+    to the lock-step host driver -- and the graph still equals the oracle's."""
+    rng = np.random.default_rng(m * 31 + dim)
+    rows = make_rows(dtype, n, dim, rng)
+    rows[700] = rows[11]
+    levels = hx.draw_levels(n, m, seed=17)
+    e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, batch, True)
+    assert elem.tolist() == oelem.tolist()
+    assert ix.fused_stats()["redone"] == 0 and ix.profile()["rounds"] == 0
+    assert_same_graph(ix, o, n)
+    qs = make_rows(dtype, 10, dim, rng)
+    e.set_queries(qs)
+    tids, d, el, cnt = ix.search(10, 40, 10)
+    for q in range(10):
+        assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=40, limit=10)]
+    ix.close()
+    e.close()
