@@ -192,7 +192,7 @@ int hx_index_batch_end(hx_index *ix, uint32_t *elem_out);
  * (what hx_index_insert does by itself whenever hx_index_dbatch_supported; the reference builds one row at a time on one core,
  * build.rs:400-535, handler.rs:153-154).  Buffers are device pointers owned by the caller -- a multi-GPU build all-gathers them
  * (RCCL) between the stages without a host copy:
- *   supported          : 1 when a batch with these level draws can run device-resident (m <= 16, rows <= 8 KiB, no level beyond the
+ *   supported          : 1 when a batch with these level draws can run device-resident (m <= 32, rows <= 8 KiB, no level beyond the
  *                        traversal kernel's 8 layers); otherwise use hx_index_batch_* for that batch
  *   record_bytes       : bytes of one member record (cnt[8] | ids[8][2m] | d[8][2m], 32-bit words)
  *   list_record_bytes  : bytes of one pruned-list record {target, layer, cnt, ids[2m], d[2m]}

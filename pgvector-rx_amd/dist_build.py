@@ -14,7 +14,7 @@ so the graph after every batch is bit-identical on all ranks and identical to th
 batch schedule.  The only data-path collectives are those two all_gathers per batch.  Batches smaller than
 `min_shard` members are built redundantly on every rank (a collective would cost more than it saves).
 
-Two exchange formats.  Device-resident (default whenever hx_index_dbatch_supported: m <= 16, rows <= 8 KiB, no level draw beyond
+Two exchange formats.  Device-resident (default whenever hx_index_dbatch_supported: m <= 32, rows <= 8 KiB, no level draw beyond
 the traversal kernel's layers): k_fused<insert> writes the members' lists into a torch-allocated DEVICE buffer, RCCL all-gathers
 that buffer, every rank scatters it into its graph copy on the device, the back-link kernels write the lists they pruned as
 device records, RCCL all-gathers those, and a kernel scatters the other ranks' records -- no list ever visits the host.  Host

@@ -599,7 +599,7 @@ def _random_cases():
         else:
             metric = [hx.L2SQ, hx.NEG_IP, hx.L1][int(rng.integers(0, 3))]
             dim = int(rng.choice([1, 3, 17, 31, 32, 33, 64, 127, 129, 200, 257, 300]))
-        m = int(rng.choice([2, 3, 5, 8, 12, 16]))                              # the device kernels serve m <= 16 (lists of <= 32)
+        m = int(rng.choice([2, 3, 5, 8, 12, 16]))                              # m in 17..32: test_m_above_16_stays_on_the_device
         efc = int(rng.choice([2 * m, 2 * m + 7, 40, 64]))
         efc = max(efc, 2 * m)
         n = int(rng.integers(250, 900))
