@@ -13,14 +13,18 @@ template <class OP, int LPR, bool ITER = false, bool POSTED = false>
 __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
 {
     const uint32_t lane = cx.lane;
+    // A greedy step (ef = 1) visits a few dozen ids: it uses the first 1 024 words of the table, so clearing costs 4 KB instead of 32-64 KB per
+    // layer of the descent (the clears were 4 % of a query's memory traffic).  Any table size gives the same visited SET; one that fills up reports
+    // FS_OVERFLOW and the task is retried with roomier tables, as for the full-size table.
+    const uint64_t vis_words = (ef == 1u && !ITER && p.vis_words > 1024u) ? 1024u : p.vis_words;
     if (fresh) {   // fresh visited set
-        for (uint64_t w = (uint64_t)lane * 4; w < p.vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
+        for (uint64_t w = (uint64_t)lane * 4; w < vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     uint32_t vcount = fresh ? 0u : cx.vcount;
     if (eps_visited) {
         vcount += n_ep;
-        for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(p.vis_words >> 2) - 1u, cx.EP[i].y);
+        for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, (uint32_t)(vis_words >> 2) - 1u, cx.EP[i].y);
     }
     // Pushes into `discarded` are only read back by a later resume, so they are queued (in the reference's order) and applied
     // per expansion.  The new slots are consecutive, so at every level their ancestors form ONE contiguous index range: those
@@ -165,7 +169,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         for (uint32_t n0 = 0; n0 < n; n0 += 64) {                                    // lists longer than a wave (m > 32) go in order
             const uint32_t idx = n0 + lane;
             uint32_t e = 0; bool unvis = false;
-            const uint32_t bmask = (uint32_t)(p.vis_words >> 2) - 1u;
+            const uint32_t bmask = (uint32_t)(vis_words >> 2) - 1u;
             uint32_t *vslot = nullptr; uint32_t vold = VIS_EMPTY;                    // insert in flight (settled below)
             if (idx < n) {
                 e = n0 == 0 ? e_first : nb[idx];
@@ -177,7 +181,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             const unsigned long long mask = __ballot(unvis);
             const uint32_t cnt = (uint32_t)__popcll(mask);
             vcount += cnt;
-            if (vcount * 4u > (uint32_t)p.vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
+            if (vcount * 4u > (uint32_t)vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
             if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
             F_BAR();
