@@ -74,7 +74,8 @@ def all_gather_device(send, world, dist, device):
         host = torch.empty(world * send.numel(), dtype=torch.uint8)
         dist.all_gather_into_tensor(host, send.cpu())
         recv.copy_(host)
-        torch.cuda.synchronize(send.device)
+        if send.is_cuda:
+            torch.cuda.synchronize(send.device)
     return recv
 
 
@@ -87,8 +88,10 @@ def _device_batch(ix, first_row, levels, tids, dist, device, gpu, world, rank):
     t0 = time.perf_counter()
     ix.dbatch_begin(first_row, levels, tids)
     t0 = _t("begin", t0)
+    on_gpu = torch.device(gpu).type == "cuda"                      # (a CPU "device" only in the CPU-side test of this exchange)
     send = torch.zeros(per * rb, dtype=torch.uint8, device=gpu)
-    torch.cuda.current_stream(gpu).synchronize()                  # the engine runs on its own (non-blocking) stream
+    if on_gpu:
+        torch.cuda.current_stream(gpu).synchronize()              # the engine runs on its own (non-blocking) stream
     ix.dbatch_search(lo, hi, send.data_ptr())
     t0 = _t("search", t0)
     recs = all_gather_device(send, world, dist, device)
@@ -98,7 +101,8 @@ def _device_batch(ix, first_row, levels, tids, dist, device, gpu, world, rank):
     sizes = gather_sizes(mine, dist, device)
     cap = max(max(sizes), 1)
     lsend = torch.zeros(cap * lb, dtype=torch.uint8, device=gpu)
-    torch.cuda.current_stream(gpu).synchronize()
+    if on_gpu:
+        torch.cuda.current_stream(gpu).synchronize()
     ix.dbatch_export_links(lsend.data_ptr())
     t0 = _t("export_links", t0)
     lrecv = all_gather_device(lsend, world, dist, device)

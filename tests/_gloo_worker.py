@@ -36,6 +36,7 @@ class FakeIndex:
         self.link_tok = {}     # target -> token of its (pruned) list
         self.calls = {"search": 0, "links_owned": 0, "replicated": 0}
         self.open = None
+        self.use_dbatch = False
 
     # --- single-GPU path: begin, search(0,b), links(0,1), end -- exactly what hx_index_insert does
     def insert(self, first_row, levels, tids, batch):
@@ -145,6 +146,54 @@ class FakeIndex:
         self.open = None
         return out
 
+    # --- device-resident staged path (hx_index_dbatch_*): same protocol, the "device" buffers are host memory reached through raw pointers
+    dbatch_record_bytes = 24
+    dbatch_list_record_bytes = 16
+
+    def dbatch_supported(self, levels):
+        return self.use_dbatch
+
+    @staticmethod
+    def _view(ptr, nbytes):
+        import ctypes
+        return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr))
+
+    def dbatch_begin(self, first_row, levels, tids):
+        self.batch_begin(first_row, levels, tids)
+
+    def dbatch_search(self, lo, hi, d_records):
+        self.batch_search(lo, hi)
+        v = self._view(d_records, (hi - lo) * self.dbatch_record_bytes).view(np.uint64).reshape(hi - lo, 3)
+        for i in range(lo, hi):
+            e = self.open["first"] + i
+            v[i - lo] = (e, self.open["levels"][i], self.new_tok[e])
+
+    def dbatch_links(self, rank, world, d_records):
+        b = len(self.open["levels"])
+        v = self._view(d_records, b * self.dbatch_record_bytes).view(np.uint64).reshape(b, 3)
+        for i in range(b):                                   # every member's record arrived, in member order, intact
+            e = self.open["first"] + i
+            assert int(v[i, 0]) == e and int(v[i, 1]) == self.open["levels"][i], (i, v[i])
+            self.new_tok[e] = int(v[i, 2])
+            self.open["got"].add(i)
+        self.batch_links(rank, world)
+        self.open["mine"] = [(t, self.link_tok[t]) for t, _ in self.open["groups"] if t % world == rank]
+        return len(self.open["mine"])
+
+    def dbatch_export_links(self, d_out):
+        m = self.open["mine"]
+        if m:
+            self._view(d_out, len(m) * self.dbatch_list_record_bytes).view(np.uint64).reshape(len(m), 2)[:] = np.asarray(m, np.uint64)
+
+    def dbatch_import_links(self, d_list_records, n):
+        v = self._view(d_list_records, n * self.dbatch_list_record_bytes).view(np.uint64).reshape(n, 2)
+        for t, tok in v.tolist():
+            assert t % self.open["world"] != self.open["rank"]
+            self.link_tok[int(t)] = int(tok)
+
+    def dbatch_end(self, b):
+        return self.batch_end(b)
+
     def digest(self):
         h = hashlib.sha256()
         for k in sorted(self.new_tok):
@@ -166,6 +215,7 @@ class OneRank:
 
 def main():
     n, batch = int(sys.argv[1]), int(sys.argv[2])
+    device_format = len(sys.argv) > 3 and sys.argv[3] == "device"
     rng = np.random.default_rng(5)
     levels = np.minimum(rng.geometric(0.75, n) - 1, 4).astype(np.int32)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,7 +225,8 @@ def main():
     else:
         d = OneRank
     ix = FakeIndex(levels)
-    elems = db.insert_sharded(ix, 0, levels, batch, d, torch.device("cpu"), min_shard=16)
+    ix.use_dbatch = device_format
+    elems = db.insert_sharded(ix, 0, levels, batch, d, torch.device("cpu"), min_shard=16, gpu=torch.device("cpu") if device_format else None)
     assert elems.tolist() == list(range(n))
     print("DIGEST %s size=%d search=%d owned=%d replicated=%d" % (ix.digest(), ix.size, ix.calls["search"], ix.calls["links_owned"], ix.calls["replicated"]), flush=True)
     if world > 1:

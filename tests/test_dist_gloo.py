@@ -23,13 +23,13 @@ def free_port():
     return p
 
 
-def run_world(world, n, batch):
+def run_world(world, n, batch, fmt="host"):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(n), str(batch)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_gloo_worker.py"), str(n), str(batch), fmt],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -39,11 +39,14 @@ def run_world(world, n, batch):
     return outs
 
 
+@pytest.mark.parametrize("fmt", ["host", "device"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_build_replicas_agree(world):
+def test_sharded_build_replicas_agree(world, fmt):
+    """fmt = the exchange format of dist_build.py: serialized host buffers (hx_index_batch_*) or device records (hx_index_dbatch_*; here the
+    "device" buffers are host memory behind raw pointers, the stand-in index checks that every record arrives where the protocol says)."""
     n, batch = 3000, 128
-    single = run_world(1, n, batch)[0]
-    outs = run_world(world, n, batch)
+    single = run_world(1, n, batch, fmt)[0]
+    outs = run_world(world, n, batch, fmt)
     assert all(o[0] == single[0] for o in outs), (single, outs)          # same state on every rank == single-rank state
     assert all(int(o[1]) == n for o in outs)
     searched = [int(o[2]) for o in outs]
