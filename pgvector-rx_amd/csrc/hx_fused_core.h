@@ -217,15 +217,24 @@ template <bool NEAREST> struct PHeap {
 // expansion have been issued) and re-insert then: the test costs one memory hop instead of one per probe.
 #define VIS_EMPTY 0xffffffffu
 __device__ __forceinline__ uint32_t vis_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+// One 16-byte load of a bucket that bypasses the vector L1 (sc1 = agent scope: the inserts are L2 atomics, an L1 copy could be stale).  A relaxed
+// agent-scope atomic load is at most 8 bytes wide, and two of them per bucket doubled the requests the visited test puts into the memory pipeline
+// (a third of an expansion's requests); a buffer load takes the cache policy as an operand.  Only this wave writes its table and never while a
+// test is in flight, so the 16 bytes need not be read atomically.  The table base is wave-uniform (one table per wave).
+__device__ __forceinline__ u4 vis_load_bucket(const uint32_t *tab, uint32_t b)
+{
+    const uint64_t a = (uint64_t)tab;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(b * 16u), 0, 16 /* sc1 */);
+}
 // true: key present.  false: *slot = the empty slot the key belongs in
 __device__ __forceinline__ bool vis_lookup(uint32_t *tab, uint32_t bmask, uint32_t key, uint32_t *&slot)
 {
     uint32_t b = vis_mix(key) & bmask;
     for (;;) {
-        const unsigned long long *bp = (const unsigned long long *)(tab + 4u * b);
-        const unsigned long long lo = __hip_atomic_load(bp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long hi = __hip_atomic_load(bp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t x = (uint32_t)lo, y = (uint32_t)(lo >> 32), z = (uint32_t)hi, w = (uint32_t)(hi >> 32);
+        const u4 bk = vis_load_bucket(tab, b);
+        const uint32_t x = bk.x, y = bk.y, z = bk.z, w = bk.w;
         if (x == key || y == key || z == key || w == key) return true;
         const int e = x == VIS_EMPTY ? 0 : (y == VIS_EMPTY ? 1 : (z == VIS_EMPTY ? 2 : (w == VIS_EMPTY ? 3 : -1)));
         if (e >= 0) { slot = tab + 4u * b + (uint32_t)e; return false; }

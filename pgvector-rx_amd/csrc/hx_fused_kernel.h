@@ -135,6 +135,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     }
     rlen = wl;
     F_BAR();
+    const uint32_t bmask = (uint32_t)(vis_words >> 2) - 1u;
     for (;;) {
         if (cx.status != FS_OK) break;
         // pop the nearest candidate, decide whether to stop
@@ -169,7 +170,6 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         for (uint32_t n0 = 0; n0 < n; n0 += 64) {                                    // lists longer than a wave (m > 32) go in order
             const uint32_t idx = n0 + lane;
             uint32_t e = 0; bool unvis = false;
-            const uint32_t bmask = (uint32_t)(vis_words >> 2) - 1u;
             uint32_t *vslot = nullptr; uint32_t vold = VIS_EMPTY;                    // insert in flight (settled below)
             if (idx < n) {
                 e = n0 == 0 ? e_first : nb[idx];
