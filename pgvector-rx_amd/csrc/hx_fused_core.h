@@ -241,6 +241,19 @@ __device__ __forceinline__ bool vis_lookup(uint32_t *tab, uint32_t bmask, uint32
         b = (b + 1u) & bmask;
     }
 }
+// vis_lookup whose home bucket `bk` was requested earlier (vis_load_bucket); valid as long as no insert of this wave happened in between
+__device__ __forceinline__ bool vis_lookup_from(uint32_t *tab, uint32_t bmask, uint32_t key, uint32_t *&slot, u4 bk)
+{
+    uint32_t b = vis_mix(key) & bmask;
+    for (;;) {
+        const uint32_t x = bk.x, y = bk.y, z = bk.z, w = bk.w;
+        if (x == key || y == key || z == key || w == key) return true;
+        const int e = x == VIS_EMPTY ? 0 : (y == VIS_EMPTY ? 1 : (z == VIS_EMPTY ? 2 : (w == VIS_EMPTY ? 3 : -1)));
+        if (e >= 0) { slot = tab + 4u * b + (uint32_t)e; return false; }
+        b = (b + 1u) & bmask;
+        bk = vis_load_bucket(tab, b);
+    }
+}
 // deferred half of an insert: `old` is what the atomicCAS on `slot` returned; re-insert while another lane won the slot
 __device__ __forceinline__ void vis_settle(uint32_t *tab, uint32_t bmask, uint32_t key, uint32_t *slot, uint32_t old)
 {

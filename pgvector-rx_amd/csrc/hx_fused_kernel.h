@@ -136,6 +136,8 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     rlen = wl;
     F_BAR();
     const uint32_t bmask = (uint32_t)(vis_words >> 2) - 1u;
+    const bool ahead = layer == 0 && (p.fdbg & 8u);
+    uint32_t pf_cid = 0xffffffffu, pf_e = 0u, pf_n = 0u;
     for (;;) {
         if (cx.status != FS_OK) break;
         // pop the nearest candidate, decide whether to stop
@@ -153,12 +155,19 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
         }
         go = __builtin_amdgcn_readfirstlane(go); cid = __builtin_amdgcn_readfirstlane(cid);
         const uint32_t *nb = p.l0_ids; uint32_t n = 0, lmax = 0, e_first = 0; int32_t clevel = 0x7fffffff;
+        bool probed = false; u4 pbk = {0u, 0u, 0u, 0u};
         if (go) {
             if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; lmax = 2u * p.m; }
             else { nb = p.up_ids + (size_t)(p.up_block[cid] + (uint32_t)(layer - 1)) * p.m; lmax = p.m; clevel = p.level[cid]; }
-            e_first = lane < lmax ? nb[lane] : 0u;                                   // issued together with the count: one memory hop
-            if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
+            if (ahead && cid == pf_cid) {                                            // the list came in during the previous replay
+                e_first = pf_e; n = pf_n; probed = true;
+                if (lane < n) pbk = vis_load_bucket(cx.vis, vis_mix(e_first) & bmask);   // in flight during the pop
+            } else {
+                e_first = lane < lmax ? nb[lane] : 0u;                               // issued together with the count: one memory hop
+                if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
+            }
         }
+        pf_cid = 0xffffffffu;
         uint2 popped = make_uint2(0u, 0u); const bool had = clen > 0;
         if (had) popped = c_pop();                                                   // mod.rs:187 (the popped element is the root read above)
         F_TICK(0);
@@ -173,7 +182,8 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             uint32_t *vslot = nullptr; uint32_t vold = VIS_EMPTY;                    // insert in flight (settled below)
             if (idx < n) {
                 e = n0 == 0 ? e_first : nb[idx];
-                unvis = !vis_lookup(cx.vis, bmask, e, vslot);                        // visited.contains / insert, mod.rs:206-209
+                if (probed && n0 == 0) unvis = !vis_lookup_from(cx.vis, bmask, e, vslot, pbk);
+                else unvis = !vis_lookup(cx.vis, bmask, e, vslot);                   // visited.contains / insert, mod.rs:206-209
                 if (unvis) vold = atomicCAS(vslot, VIS_EMPTY, e);
                 if (unvis && layer > 0 && p.level[e] < layer) unvis = false;         // mod.rs:213-216
             }
@@ -202,6 +212,22 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             unsigned long long km = ITER ? __ballot(lane < cnt) : __ballot(keep);     // ITER: rejected rows are visited too (they go to `discarded`)
             F_TICK(5);
             F_BAR();
+            if (ahead && n0 + 64u >= n && clen <= cx.CH.L) {                         // look-ahead: who is popped next?
+                float best = 0.0f; uint32_t bid = 0u; bool have = false;
+                if (clen > 0) { const uint2 r = PHeap<true>::ld(CA, 0u); best = fh_d(r); bid = r.y; have = true; }
+                unsigned long long cm = __ballot(keep && (!have || mine < best));
+                while (cm) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(cm); cm &= cm - 1ull;
+                    const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), (int)j));
+                    if (!have || dj < best) { best = dj; bid = cx.IDS[j]; have = true; }
+                }
+                if (have) {
+                    bid = (uint32_t)__builtin_amdgcn_readfirstlane((int)bid);
+                    pf_cid = bid;
+                    pf_e = lane < 2u * p.m ? p.l0_ids[(size_t)bid * 2u * p.m + lane] : 0u;
+                    pf_n = p.l0_cnt[bid];
+                }
+            }
             while (km) {                                                             // replay in list order, mod.rs:226-243 / scan.rs:372-429
                 const uint32_t j = (uint32_t)__builtin_ctzll(km); km &= km - 1ull;
                 const uint2 it = cx.RES[j]; const float d = fh_d(it);

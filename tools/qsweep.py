@@ -1,5 +1,5 @@
 """QPS of the fused scan kernel vs queries per launch (tail / residency quantisation check).  python tools/qsweep.py [rows]"""
-import json, sys, time
+import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 import pgvector_rx_amd as hx
@@ -14,7 +14,7 @@ eng.append_device(rows.data_ptr(), n)
 ix = hx.Index(eng, m, efc)
 t0 = time.perf_counter(); ix.insert(0, hx.draw_levels(n, m, seed=1), batch=8192); print("build", round(time.perf_counter() - t0, 2), flush=True)
 eng.set_timing(True)
-for nq in (256, 1024, 3840, 7680, 10000, 20000, 40000):
+for nq in [int(x) for x in os.environ.get('HX_QSWEEP', '256,1024,3840,7680,10000,20000,40000').split(',')]:
     eng.set_queries_device(qs.data_ptr(), nq)
     ix.search(nq, efs, k); eng.kernel_stats(2, reset=True)
     t0 = time.perf_counter()
