@@ -133,6 +133,8 @@ int hx_engine::mirror_download(uint64_t n_elems, uint64_t n_blocks, uint32_t *l0
     return HX_OK;
 }
 
+static int fused2_env_on() { static const int v = getenv("HX_FUSED2") ? atoi(getenv("HX_FUSED2")) : 0; return v; }
+
 // mode 0: ntasks queries -> out_ids/out_d [ntasks][k], out_cnt[ntasks]; mode 1: ntasks inserts -> out_ids/out_d
 // [ntasks][FUSED_MAXL][2m], out_cnt [ntasks][FUSED_MAXL].  status[ntasks].  All host pointers.
 int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
@@ -158,7 +160,12 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     uint32_t iter_per_cu = 14u;
     if (mode == 2) { const char *a = getenv("HX_DISC_LDS"), *b = getenv("HX_ITER_PER_CU"); if (a && atoi(a) > 0) disc_lds = (uint32_t)atoi(a); if (b && atoi(b) > 0) iter_per_cu = (uint32_t)atoi(b); }   // tuning knobs
     { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
-    clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
+    // HX_SORTED_ARRAY=1 (opt-in experiment, hx_fused_kernel.h: f_search_layer_sa): first launches of queries search on one sorted array; a query that
+    // meets a tie reports FS_OVERFLOW and its retry launch (roomy > 1) uses the heap kernel, which is exact for any input
+    const int sa_env = getenv("HX_SORTED_ARRAY") ? atoi(getenv("HX_SORTED_ARRAY")) : 0;
+    const bool sa = sa_env && roomy == 1 && mode == 0 && dtype != HX_BIT && ef > 1 && ef <= 256 && !fused2_env_on();
+    if (sa) clds = 0;                                            // no candidate heap
+    if (!sa) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
     if (dev && dev->d_wtab) clds = std::max<uint32_t>(clds, dev->wt_size);                     // so does the W table
     auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };
     const size_t lds = lds_bytes(clds);
@@ -167,7 +174,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     { const char *pv = getenv(mode == 0 ? "HX_QUERY_PER_CU" : "HX_INSERT_PER_CU"); if (mode != 2 && pv && atoi(pv) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(pv)); }   // tuning knob
     uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
     // k_fused2 (rows wider than 512 B, queries and inserts): one 1024-thread workgroup per CU, nc control waves + (16 - nc) stream waves
-    static const int fused2_env = getenv("HX_FUSED2") ? atoi(getenv("HX_FUSED2")) : 0;   // experimental pooled-stream kernel: opt-in (measured slower than one wave per search so far)
+    const int fused2_env = fused2_env_on();   // experimental pooled-stream kernel: opt-in (measured slower than one wave per search so far)
     const uint32_t slot_bytes = (uint32_t)((lds + 15) & ~(size_t)15);
     uint32_t nc2 = 0;
     if (fused2_env && mode != 2 && pitch > 512 && ntasks >= 64) {
@@ -266,6 +273,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     if (mode == 2) { p.iter_mode = (uint32_t)it->iter_mode; p.max_tuples = it->max_tuples; p.emask = mr.d_emask; p.disc = (unsigned long long *)mr.d_disc; p.disc_stride = (uint32_t)disc_stride; }
     p.spill = (uint2 *)spill_ptr; p.spill_stride = ccap;
     { const char *dv = getenv("HX_F_DBG"); p.fdbg = dv ? (uint32_t)atoi(dv) : 0u; }
+    p.sa = sa ? 1u : 0u;
     p.vis = vis_ptr ? vis_ptr : mr.d_vis; p.vis_words = vis_words;
     p.next_task = (uint32_t *)(mr.d_io + o_ctr);
     p.n_dist = (unsigned long long *)(mr.d_io + o_ctr + 8);
@@ -307,7 +315,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     if (mode == 2) memcpy(it->out_tix, mr.h_io + o_tix, out_n * 4);
     unsigned long long nd[17]; memcpy(nd, mr.h_io + o_ctr + 8, 136);
     if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))
-        fprintf(stderr, "[hx] k_fused mode %d tasks %u: 100 MHz ticks summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu; select phase %llu\n",
+        fprintf(stderr, "[hx] k_fused mode %d tasks %u: shader-clock ticks (s_memtime) summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu; select phase %llu\n",
                 mode, ntasks, nd[3], nd[4], nd[5], nd[6], nd[7], nd[8], nd[9], nd[10], nd[11], nd[12], nd[13], nd[14], nd[15], nd[16]);
     if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }
     if (nd[2] > fused_cmax) fused_cmax = nd[2];

@@ -12,6 +12,9 @@
 #ifndef FUSED_MINW
 #define FUSED_MINW 4
 #endif
+#ifndef FUSED_MINW_SA
+#define FUSED_MINW_SA 4             /* the sorted-array query kernel */
+#endif
 #ifndef FUSED_MINW_INS
 #define FUSED_MINW_INS 3            /* insert-mode kernel: 168 VGPRs, no spills (13 searches per CU are LDS-limited anyway); measured +2 % over 4 */
 #endif
@@ -46,6 +49,7 @@ struct FusedParams {
     unsigned long long *disc; uint32_t disc_stride, disc_lds;   // per-workgroup tail of the `discarded` heap (entries), its LDS head
     uint32_t *out_tix;                            // which heap TID of the element each output is
     float *dsc;                                   // 64 floats of LDS scratch for the short-row distance path (set inside the kernels)
+    uint32_t sa;                                  // 1: searches with ef > 1 run on one sorted array (f_search_layer_sa); ties are redone by the heap kernel
     uint32_t fdbg;                                // experiments (HX_F_DBG): 1 no pre-filter, 4 phase timers into n_dist[3..7]
 };
 
@@ -423,21 +427,35 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
             for (int k = 0; k < FUSED_CG; k++) {
                 if ((uint32_t)k < kc) {
                     const u4 q = *(const u4 *)(qv + (c0 + (uint32_t)k) * 1024u + loff);
+                    if (ragged && c0 + (uint32_t)k + 1u == p.nch) {                 // the row's partial last chunk: lanes past the payload contribute zeros
 #pragma unroll
-                    for (int r = 0; r < RB; r++) {
-                        u4 v = rv[r][k];
-                        if (ragged && !ink[k]) v = u4{0u, 0u, 0u, 0u};
-                        OP::add(acc[r], q, v);
+                        for (int r = 0; r < RB; r++) {
+                            u4 v = rv[r][k];
+                            if (!ink[k]) v = u4{0u, 0u, 0u, 0u};
+                            OP::add(acc[r], q, v);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < RB; r++) OP::add(acc[r], q, rv[r][k]);
                     }
                 }
             }
             if (tk) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             FD_TICK(11);                                  // arithmetic
         }
+        if constexpr (OP::kFloatAcc && RB == 4) {           // the four rows' butterflies share their steps (hx_ops.h: lanes_sum4_f)
+            const float z = lanes_sum4_f(acc[0], acc[1], acc[2], acc[3]);
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
-            const float d = OP::template finish<64>(acc[r]);
-            if (j0 + r < n && lane == j0 + r) mine = d;
+            for (int r = 0; r < 4; r++) {
+                const float d = OP::post(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), lanes_sum4_lane(r))));
+                if (j0 + r < n && lane == j0 + r) mine = d;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                const float d = OP::template finish<64>(acc[r]);
+                if (j0 + r < n && lane == j0 + r) mine = d;
+            }
         }
         FD_TICK(12);                                      // reductions
     }

@@ -262,6 +262,150 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     F_BAR();
 }
 
+// search_layer / search_layer_disk on ONE sorted array (the `SA` kernels; SURVEY 8 row a1 / a4, same results as f_search_layer).
+//
+// Without ties the two heaps of Algorithm 2 carry redundant state: every element of C was pushed to W at the same moment (mod.rs:236-241), an element
+// that W evicted is at least as far as everything W keeps and W's furthest only moves closer, so it fails the stop test `c.d > f.d` (mod.rs:188-193)
+// whenever it reaches C's root -- the candidates that can still be expanded are exactly the unexpanded members of W.  The kernel therefore keeps W as
+// an ascending array in LDS with an "expanded" flag per entry (bit 31 of the id): the next candidate is the first unflagged entry (K = ceil(ef/64)
+// ballots), the search ends when there is none, and the rows of an expansion are merged in together -- each entry counts the new rows in front of it,
+// each new row the entries and new rows in front of it, one round of LDS writes -- instead of a sift per push and per eviction.  Replaying the list in
+// order (mod.rs:226-243) leaves the ef nearest of W + the rows that pass `d < f.d`; so does the merge.
+// A TIE changes that: which of two equal distances a binary heap pops first depends on its array, and an evicted element at exactly W's furthest
+// distance would still be expanded.  Every pair of equal distances that meets inside W is adjacent in the array when the second one arrives, so the
+// merge sees it; the search then reports FS_OVERFLOW and the task is redone by the heap kernel (k_fused<.., SA = false>, the retry launch), which
+// reproduces Rust's BinaryHeap bit by bit.  Integer-valued metrics (Hamming, Jaccard) tie all the time and never take this path.
+//
+// Measured (1M x 768, 10 000 queries, profiles/r02_rocprofv3_pmc_insts_sa*.txt): 39 % fewer VALU and 34 % fewer SALU instructions per expansion, 102
+// VGPRs without scratch, no candidate heap in LDS; the launch takes 7.5 ms instead of 9.3.  But 4.5 % of the queries meet a tie -- two of a search's
+// ~1 700 f32 distances coincide more often than one would think -- and their retry launch is one search latency long (3.9 ms) however few they are;
+// redoing them inside the same kernel needs the heap code and its registers next to this one and was slower than the heap kernel alone.
+// Opt-in: HX_SORTED_ARRAY=1.
+template <class OP, int LPR, bool POSTED>
+__device__ void f_search_layer_sa(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer)
+{
+    constexpr uint32_t XF = 0x80000000u;
+    const uint32_t lane = cx.lane;
+    const uint64_t vis_words = (ef == 1u && p.vis_words > 1024u) ? 1024u : p.vis_words;      // as f_search_layer: a greedy step touches a few dozen ids
+    for (uint64_t w = (uint64_t)lane * 4; w < vis_words; w += 256) *(u4 *)(cx.vis + w) = u4{VIS_EMPTY, VIS_EMPTY, VIS_EMPTY, VIS_EMPTY};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t bmask = (uint32_t)(vis_words >> 2) - 1u;
+    uint32_t vcount = n_ep;
+    for (uint32_t i = lane; i < n_ep; i += 64) (void)vis_test_and_set(cx.vis, bmask, cx.EP[i].y);
+    lds_uint2 *const A = (lds_uint2 *)cx.W;
+    const uint32_t K = (ef + 63u) >> 6;                                  // <= 4 (the host keeps ef <= 256 on this path)
+    // the entry points arrive ascending (one element, or the previous layer's result); anything else goes to the heap kernel
+    bool bad = n_ep > ef;
+    for (uint32_t i = lane; i < n_ep; i += 64) {
+        const uint2 e = cx.EP[i];
+        if (i + 1u < n_ep && !(fh_d(e) < fh_d(cx.EP[i + 1u]))) bad = true;
+        A[i].x = e.x; A[i].y = e.y;
+    }
+    if (__ballot(bad) != 0ull) cx.status = FS_OVERFLOW;
+    uint32_t len = n_ep;
+    F_BAR();
+    while (cx.status == FS_OK) {
+        const bool tm = (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+        // the nearest unexpanded member of W (mod.rs:187-193)
+        uint32_t pos = 0xffffffffu;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            if (k < K) {
+                const uint32_t i = lane + 64u * k;
+                const bool un = i < len && !(A[i].y & XF);
+                const unsigned long long um = __ballot(un);
+                if (um != 0ull && pos == 0xffffffffu) pos = 64u * k + (uint32_t)__builtin_ctzll(um);
+            }
+        }
+        if (pos == 0xffffffffu) break;
+        const uint32_t cid = (uint32_t)__builtin_amdgcn_readfirstlane((int)A[pos].y);
+        const uint32_t *nb; uint32_t n, lmax; int32_t clevel = 0x7fffffff;
+        if (layer == 0) { nb = p.l0_ids + (size_t)cid * 2u * p.m; lmax = 2u * p.m; }
+        else { nb = p.up_ids + (size_t)(p.up_block[cid] + (uint32_t)(layer - 1)) * p.m; lmax = p.m; clevel = p.level[cid]; }
+        const uint32_t e_first = lane < lmax ? nb[lane] : 0u;
+        if (layer == 0) n = p.l0_cnt[cid]; else n = p.up_cnt[p.up_block[cid] + (uint32_t)(layer - 1)];
+        if (lane == 0) A[pos].y = cid | XF;
+        F_TICK(0);
+        if (tm) cx.tph[7]++;
+        if (layer > 0 && clevel < layer) continue;                               // mod.rs:198-200
+        for (uint32_t n0 = 0; n0 < n; n0 += 64) {
+            const uint32_t idx = n0 + lane;
+            uint32_t e = 0; bool unvis = false;
+            uint32_t *vslot = nullptr; uint32_t vold = VIS_EMPTY;
+            if (idx < n) {
+                e = n0 == 0 ? e_first : nb[idx];
+                unvis = !vis_lookup(cx.vis, bmask, e, vslot);                    // mod.rs:206-209
+                if (unvis) vold = atomicCAS(vslot, VIS_EMPTY, e);
+                if (unvis && layer > 0 && p.level[e] < layer) unvis = false;     // mod.rs:213-216
+            }
+            F_TICK(2);
+            const unsigned long long mask = __ballot(unvis);
+            const uint32_t cnt = (uint32_t)__popcll(mask);
+            vcount += cnt;
+            if (vcount * 4u > (uint32_t)vis_words * 3u) { cx.status = FS_OVERFLOW; break; }
+            if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
+            if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
+            F_BAR();
+            F_TICK(3);
+            const float mine = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
+            F_TICK(4);
+            vis_settle(cx.vis, bmask, e, vslot, vold);
+            cx.nd0 += cnt;
+            // rows that can enter W: all of them while W is short of ef, else those nearer than its furthest member (mod.rs:226-232)
+            const bool full = len >= ef;
+            const float fmax = len ? __builtin_bit_cast(float, (unsigned int)A[len - 1u].x) : 0.0f;
+            const bool keep = lane < cnt && (!full || mine < fmax);
+            unsigned long long km = __ballot(keep);
+            F_TICK(5);
+            if (km != 0ull) {
+                const uint32_t nk = (uint32_t)__popcll(km);
+                const uint32_t myid = lane < cnt ? cx.IDS[lane] : 0u;
+                uint2 v[4]; uint32_t sh[4]; bool valid[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) {
+                    const uint32_t i = lane + 64u * k;
+                    valid[k] = k < K && i < len; sh[k] = 0u;
+                    v[k] = valid[k] ? make_uint2(A[i].x, A[i].y) : make_uint2(0u, 0u);
+                }
+                bool tie = false; uint32_t mypos = 0u;
+                while (km) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(km); km &= km - 1ull;
+                    const float dj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), (int)j));
+                    uint32_t before = 0u;                                         // members of W in front of row j
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; k++) {
+                        if (k < K) {
+                            const float dk = fh_d(v[k]);
+                            const bool gt = valid[k] && dk > dj;
+                            tie |= valid[k] && dk == dj;
+                            sh[k] += gt ? 1u : 0u;
+                            before += (uint32_t)__popcll(__ballot(valid[k] && !gt));
+                        }
+                    }
+                    before += (uint32_t)__popcll(__ballot(keep && mine < dj));    // new rows in front of row j
+                    tie |= keep && mine == dj && lane != j;
+                    if (lane == j) mypos = before;
+                }
+                if (__ballot(tie) != 0ull) { cx.status = FS_OVERFLOW; break; }
+                F_WSYNC();
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) {
+                    const uint32_t i = lane + 64u * k + sh[k];
+                    if (valid[k] && sh[k] != 0u && i < ef) { A[i].x = v[k].x; A[i].y = v[k].y; }
+                }
+                if (keep && mypos < ef) { A[mypos].x = __builtin_bit_cast(unsigned int, mine); A[mypos].y = myid; }
+                len = len + nk < ef ? len + nk : ef;
+                if (tm) cx.tph[8] += nk;
+                F_WSYNC();
+            }
+            F_TICK(6);
+        }
+    }
+    for (uint32_t i = lane; i < len; i += 64) A[i].y &= ~XF;
+    if (lane == 0) cx.CTL[1] = len;
+    F_BAR();
+}
+
 // stable sort of the W heap's internal array into EP: ascending (build, mod.rs:248-254) or descending (scan.rs:441-446);
 // rank sort: ties keep their order in W's array, exactly what a stable sort of that array does
 __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
@@ -281,7 +425,7 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
 // One search after the other, from the task counter, driven by ONE wavefront whose state lives in the LDS slot `lds` (`slot` selects its
 // visited table / spill area / discarded heap in global memory).  MODE 0: query (get_scan_items), 1: insert (find_element_neighbors),
 // 2: iterative scan; LPR: lanes per row (64, or 8/32 for short rows); POSTED: rows are evaluated by the workgroup's stream waves (k_fused2).
-template <class OP, int MODE, int LPR, bool POSTED>
+template <class OP, int MODE, int LPR, bool POSTED, bool SA = false>
 __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *lds_base, const uint32_t slot, const uint32_t lane_in,
                                          const uint32_t slot_bytes = 0, const uint32_t sq_off = 0, const uint32_t dout_off = 0, const uint32_t nc = 1, const uint32_t my_slot = 0)
 {
@@ -342,6 +486,12 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
         const int stop_above = MODE == 1 ? new_level : 0;
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
+            if constexpr (SA) {
+                f_search_layer_sa<OP, LPR, POSTED>(p, cx, n_ep, 1u, lc);
+                if (cx.CTL[1] > 0) { const uint2 best = cx.W[0]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); n_ep = 1; }
+                else if (MODE != 1) { n_ep = 0; break; }
+                continue;
+            }
             f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, 1u, lc, MODE != 1);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
@@ -407,6 +557,15 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
         } else if (MODE == 0) {
             uint32_t cnt = 0;
             if (cx.status == FS_OK && n_ep > 0) {
+                if constexpr (SA) {
+                    f_search_layer_sa<OP, LPR, POSTED>(p, cx, n_ep, p.ef, 0);                        // scan.rs:515-528; W comes out ascending
+                    const uint32_t wl = cx.CTL[1];
+                    cnt = cx.status != FS_OK ? 0u : wl < p.k ? wl : p.k;
+                    for (uint32_t i = lane; i < cnt; i += 64) {
+                        const uint2 v = cx.W[i];
+                        p.out_ids[(size_t)t * p.k + i] = v.y; p.out_d[(size_t)t * p.k + i] = fh_d(v);
+                    }
+                } else {
                 f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, true);                                        // nearest LAST
@@ -414,6 +573,7 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
                 for (uint32_t i = lane; i < cnt; i += 64) {                          // amgettuple pops from the back
                     const uint2 v = cx.EP[wl - 1 - i];
                     p.out_ids[(size_t)t * p.k + i] = v.y; p.out_d[(size_t)t * p.k + i] = fh_d(v);
+                }
                 }
             }
             if (lane == 0) { p.out_cnt[t] = cnt; p.status[t] = cx.status; }
@@ -512,13 +672,13 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
                      if (p.fdbg & 4u) { for (int i = 0; i < 14; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
 }
 
-template <class OP, int MODE, int LPR>
-__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : MODE == 1 ? FUSED_MINW_INS : FUSED_MINW))
+template <class OP, int MODE, int LPR, bool SA = false>
+__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : MODE == 1 ? FUSED_MINW_INS : SA ? FUSED_MINW_SA : FUSED_MINW))
 k_fused(const FusedParams p_in)
 {
     FusedParams p = p_in;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    f_worker<OP, MODE, LPR, false>(p, lds, lds, blockIdx.x, threadIdx.x);
+    f_worker<OP, MODE, LPR, false, SA>(p, lds, lds, blockIdx.x, threadIdx.x);
 }
 
 // k_fused2: nc control waves (one search each, f_worker<POSTED>) + stream waves (f_stream_loop) per 1024-thread workgroup; see hx_fused_core.h
@@ -544,21 +704,21 @@ k_fused2(const FusedParams p_in, const uint32_t nc, const uint32_t slot_bytes)
     }
 }
 
-template <class OP, int MODE, int LPR>
+template <class OP, int MODE, int LPR, bool SA = false>
 static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds)
 {
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        hipError_t s = hipFuncSetAttribute((const void *)k_fused<OP, MODE, LPR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        hipError_t s = hipFuncSetAttribute((const void *)k_fused<OP, MODE, LPR, SA>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         if (s != hipSuccess) return s;
         attr_set = true;
     }
     if (getenv("HX_DEBUG")) {
         static thread_local bool once = false;
-        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_fused<OP, MODE, LPR>, 64, lds);
-            fprintf(stderr, "[hx] k_fused<mode %d, %d lanes/row>: dynamic LDS %zu B, grid %u, occupancy API says %d blocks/CU\n", MODE, LPR, lds, grid, nb); }
+        if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_fused<OP, MODE, LPR, SA>, 64, lds);
+            fprintf(stderr, "[hx] k_fused<mode %d, %d lanes/row, sorted-array %d>: dynamic LDS %zu B, grid %u, occupancy API says %d blocks/CU\n", MODE, LPR, (int)SA, lds, grid, nb); }
     }
-    hipLaunchKernelGGL((k_fused<OP, MODE, LPR>), dim3(grid), dim3(64), lds, e->stream, p);
+    hipLaunchKernelGGL((k_fused<OP, MODE, LPR, SA>), dim3(grid), dim3(64), lds, e->stream, p);
     return hipGetLastError();
 }
 
@@ -584,6 +744,7 @@ template <class OP, int LPR>
 static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
 {
     if (mode == 2) return launch_fused<OP, 2, LPR>(e, p, grid, lds);
+    if constexpr (OP::sorted_array_ok) { if (p.sa && mode == 0) return launch_fused<OP, 0, LPR, true>(e, p, grid, lds); }
     return mode == 0 ? launch_fused<OP, 0, LPR>(e, p, grid, lds) : launch_fused<OP, 1, LPR>(e, p, grid, lds);
 }
 template <class OP>

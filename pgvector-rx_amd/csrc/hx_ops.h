@@ -53,6 +53,22 @@ template <int LPR, int OFF> __device__ __forceinline__ int lanes_sum_i_step(int 
     if constexpr (OFF > 1) return lanes_sum_i_step<LPR, OFF / 2>(v); else return v;
 }
 template <int LPR> __device__ __forceinline__ float lanes_sum_f(float v) { return lanes_sum_f_step<LPR, 32>(v); }
+// Four 64-lane sums at once, each by the very same butterfly tree: at the xor-32 step the two halves of a wave can work on different values
+// (v_permlane32_swap(a, b) hands lanes 0-31 both halves of a and lanes 32-63 both halves of b), at the xor-16 step the four 16-lane rows likewise,
+// and the steps inside a row then reduce all four together: 3 swaps + 7 adds + 4 row steps instead of 4 x (6 exchanges + 6 adds).
+// Returns z with sum(a0) in lanes 0-15, sum(a2) in 16-31, sum(a1) in 32-47, sum(a3) in 48-63 (lanes_sum4_lane(r) = a lane that holds sum(a_r)).
+__device__ __forceinline__ float lanes_sum4_f(float a0, float a1, float a2, float a3)
+{
+    auto f = [](unsigned int u) { return __builtin_bit_cast(float, u); };
+    auto u = [](float x) { return __builtin_bit_cast(unsigned int, x); };
+    const auto r01 = __builtin_amdgcn_permlane32_swap(u(a0), u(a1), false, false);      // {a0.lo | a1.lo}, {a0.hi | a1.hi}
+    const auto r23 = __builtin_amdgcn_permlane32_swap(u(a2), u(a3), false, false);
+    const float p = f(r01[0]) + f(r01[1]), q = f(r23[0]) + f(r23[1]);                    // lanes 0-31: a0 (a2) folded once, lanes 32-63: a1 (a3)
+    const auto rr = __builtin_amdgcn_permlane16_swap(u(p), u(q), false, false);          // rows {p0 q0 p2 q2}, {p1 q1 p3 q3}
+    const float z = f(rr[0]) + f(rr[1]);                                                 // rows: a0, a2, a1, a3 folded twice
+    return lanes_sum_f_step<64, 8>(z);
+}
+__device__ __forceinline__ constexpr int lanes_sum4_lane(int r) { return r == 0 ? 0 : r == 1 ? 32 : r == 2 ? 16 : 48; }
 template <int LPR> __device__ __forceinline__ int lanes_sum_i(int v) { return lanes_sum_i_step<LPR, 32>(v); }
 
 // ---- per-(dtype, metric) operators: add() consumes one 16-byte fragment pair, finish() reduces ----
@@ -66,6 +82,7 @@ template <int KIND> __device__ __forceinline__ void fterm(float &acc, float x, f
 }
 
 template <int KIND> struct OpF32 {
+    static constexpr bool sorted_array_ok = true;    // real-valued distances: ties are rare enough for k_fused's sorted-array searches
     typedef float acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
     static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)
@@ -83,6 +100,7 @@ template <int KIND> struct OpF32 {
 };
 
 template <int KIND> struct OpF16 {
+    static constexpr bool sorted_array_ok = true;
     typedef float acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
     static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)
@@ -103,6 +121,7 @@ template <int KIND> struct OpF16 {
 };
 
 struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
+    static constexpr bool sorted_array_ok = false;   // integer-valued: ties everywhere, the heap kernels only
     typedef int acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a = 0; }
     static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)
@@ -117,6 +136,7 @@ struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
 
 struct JacAcc { int ab, aa, bb; };
 struct OpJaccard {   // bitvec.rs:113-132
+    static constexpr bool sorted_array_ok = false;
     typedef JacAcc acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a.ab = a.aa = a.bb = 0; }
     static __device__ __forceinline__ void add(acc_t &acc, const u4 &a, const u4 &b)

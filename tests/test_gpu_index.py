@@ -666,6 +666,40 @@ def test_overflowed_tasks_are_retried_on_the_device_with_roomier_tables():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("dtype,metric,dim", [(hx.F32, hx.L2SQ, 24), (hx.F16, hx.NEG_IP, 40), (hx.F32, hx.L1, 300)])
+def test_sorted_array_search_equals_the_heap_search(dtype, metric, dim, ties):
+    """HX_SORTED_ARRAY=1: queries search on one sorted array (f_search_layer_sa) and a query that meets two equal distances is redone by the
+    heap kernel.  Small-integer coordinates make distances collide all the time (ties=True): both branches must give the oracle's answers."""
+    import os
+    rng = np.random.default_rng(dim + (7 if ties else 0))
+    n, m, efc = 3000, 12, 48
+    if ties:
+        base = rng.integers(-2, 3, size=(n + 40, dim))
+        base[100] = base[7]
+        allr = base.astype(np.float16).view(np.uint16) if dtype == hx.F16 else base.astype(np.float32)
+        rows, qs = np.ascontiguousarray(allr[:n]), np.ascontiguousarray(allr[n:])
+    else:
+        rows, qs = make_rows(dtype, n, dim, rng), make_rows(dtype, 40, dim, rng)
+    levels = hx.draw_levels(n, m, seed=5)
+    e, ix, _, o, _ = build_both(dtype, metric, dim, rows, levels, m, efc, 256)
+    e.set_queries(qs)
+    ref = ix.search(40, 64, 10)
+    os.environ["HX_SORTED_ARRAY"] = "1"
+    try:
+        got = ix.search(40, 64, 10)
+    finally:
+        del os.environ["HX_SORTED_ARRAY"]
+    assert ix.fused_stats()["redone"] == 0                           # ties are redone on the device, not by the lock-step driver
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    for q in range(40):
+        assert got[0][q, :got[3][q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=64, limit=10)]
+    ix.close()
+    e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,metric,dim,n,m,efc,batch", [(hx.F32, hx.L2SQ, 8, 1500, 20, 48, 64), (hx.F32, hx.NEG_IP, 12, 1200, 32, 64, 100), (hx.BIT, hx.HAMMING, 96, 1000, 24, 64, 37)])
 def test_m_above_16_stays_on_the_device(dtype, metric, dim, n, m, efc, batch):
     """m in 17..32 (lists of up to 64): traversal, back-link kernels (64-slot build) and the batch pipeline all run on the device -- nothing falls
