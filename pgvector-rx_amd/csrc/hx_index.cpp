@@ -1484,15 +1484,22 @@ int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_recor
     if (hi == lo) return HX_OK;
     if (!d_records) return ix->fail(HX_E_ARG, "d_records is NULL");
     const uint32_t n = hi - lo, rw = hx_rec_words((uint32_t)g.m);
-    std::vector<uint32_t> qsel(n), status(n); std::vector<int32_t> tl(n);
-    for (uint32_t i = 0; i < n; i++) { qsel[i] = bs.base + lo + i; tl[i] = g.level[bs.base + lo + i]; }
+    // Longest tasks first: a member with a higher level searches (and selects on) more layers, and a long task that starts in the launch's last round
+    // is what the whole chip then waits for.  The kernel pulls tasks in list order and addresses every output through the task's slot, so the order
+    // is free (HX_TASK_ORDER=0: member order).
+    std::vector<uint32_t> qsel(n), status(n), tstat(n), slots(n); std::vector<int32_t> tl(n);
+    for (uint32_t i = 0; i < n; i++) slots[i] = i;
+    static const int order_env = getenv("HX_TASK_ORDER") ? atoi(getenv("HX_TASK_ORDER")) : 1;
+    if (order_env) std::stable_sort(slots.begin(), slots.end(), [&](uint32_t a, uint32_t b) { return g.level[bs.base + lo + a] > g.level[bs.base + lo + b]; });
+    for (uint32_t k = 0; k < n; k++) { qsel[k] = bs.base + lo + slots[k]; tl[k] = g.level[bs.base + lo + slots[k]]; }
     uint64_t cnts[2] = {0, 0};
-    HxFusedDev dev; dev.d_rec = (uint32_t *)d_records; dev.rec_words = rw;
+    HxFusedDev dev; dev.d_rec = (uint32_t *)d_records; dev.rec_words = rw; dev.h_slots = slots.data();
     if (ix->e->bw.wt_size) { dev.d_wtab = ix->e->bw.d_wtab; dev.wt_size = ix->e->bw.wt_size; dev.wt_slot0 = lo; dev.d_wt_valid = ix->e->bw.d_wt_valid; }
     int rc;
     const double t0 = hx_index::now_s();
     if ((rc = ix->e->fused_run(1, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
-                               nullptr, nullptr, nullptr, status.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, ix->e->err);
+                               nullptr, nullptr, nullptr, tstat.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, ix->e->err);
+    for (uint32_t k = 0; k < n; k++) status[slots[k]] = tstat[k];
     ix->prof[6] += hx_index::now_s() - t0;
     ix->counters[1] += cnts[0]; ix->counters[2] += cnts[1];
     std::vector<uint32_t> again, todo;
