@@ -3,7 +3,7 @@
 tests/golden/recall_parity_100k.json holds recall@10 of the oracle's strictly sequential build (one row at a time, the reference's own
 summation order) on 100 000 x vector(768) L2, m = 16, ef_construction = 200 -- BASELINE configs[1]'s shape; it was produced once on a CPU by
 tools/make_recall_fixture.py (10 minutes of one core) together with the hit count of every query.  Here the same rows, levels and
-queries go through the device build with the bench's batch cap (8192: 'snapshot' batches, a NON-reference schedule) and the device scan;
+queries go through the device build with the bench's batch cap (32768, at this size every batch is the maximal 1/8 of the graph: 'snapshot' batches, a NON-reference schedule) and the device scan;
 the two graphs differ, so recall is compared query by query: the mean difference must vanish within 2 sigma of its own sampling noise
 (plus a 0.002 floor), at every ef_search of the fixture."""
 import importlib.util
@@ -30,7 +30,7 @@ def test_batched_device_build_recall_equals_sequential_reference_schedule(record
     e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
     e.append(rows)
     ix = hx.Index(e, fx["m"], fx["ef_construction"])
-    ix.insert(0, levels, batch=8192)
+    ix.insert(0, levels, batch=32768)
     assert ix.fused_stats()["redone"] == 0
     import torch
     r, q = torch.from_numpy(rows).cuda().double(), torch.from_numpy(qs).cuda().double()
@@ -46,7 +46,7 @@ def test_batched_device_build_recall_equals_sequential_reference_schedule(record
         diff = (dev_hits - ref_hits) / k
         sem = diff.std(ddof=1) / np.sqrt(len(diff))
         record_property("ef_search_%s" % efs, {"device": dev_hits.mean() / k, "reference_schedule": ref["mean"], "diff": diff.mean(), "sem": sem})
-        print("\nef_search %s: recall@%d device (batch 8192) %.4f, sequential reference schedule %.4f, paired difference %+.4f +- %.4f"
+        print("\nef_search %s: recall@%d device (batch cap 32768, i.e. size/8 here) %.4f, sequential reference schedule %.4f, paired difference %+.4f +- %.4f"
               % (efs, k, dev_hits.mean() / k, ref["mean"], diff.mean(), sem))
         assert abs(diff.mean()) <= 2.0 * sem + 0.002, (efs, diff.mean(), sem)
     ix.close()

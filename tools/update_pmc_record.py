@@ -26,13 +26,14 @@ def main():
         if m:
             k = m.group(1).strip()
             mean[k], total[k] = float(m.group(3)), float(m.group(4))
-    q = next(k for k in mean if k.startswith("void k_fused<OpF32<0>, 0, 64>"))
+    q = next(k for k in mean if k.startswith("void k_fused<OpF32<0>, 0, 64, false>") or k.startswith("void k_fused<OpF32<0>, 0, 64>"))
     k1 = next((k for k in mean if "k_dist_groups" in k), None)
     rec_path = os.path.join(ROOT, "profiles", "pmc_k_fused_query.json")
     rec = json.load(open(rec_path))
     rec["fetch_size_kb_per_launch_raw"] = mean[q]
     rec["hbm_bytes_per_launch"] = int(mean[q] * 1024 * 2)
-    rec["source"] = "%s: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --no-cpu --no-k1-1536 --steps 2 (own pass)" % os.path.relpath(path, ROOT)
+    rec["kernel"] = q.split("(")[0].replace("void ", "")
+    rec["source"] = "%s: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --no-cpu --no-k1-1536 --no-query-sweep --steps 2 (own pass)" % os.path.relpath(path, ROOT)
     rec["csrc_sha16"] = csrc_hash()
     keep = rec.get("build_kernels_fetch_size_kb_total_raw", {}).get("round1_k_links_cached")
     rec["build_kernels_fetch_size_kb_total_raw"] = {k.split("(")[0].replace("void ", ""): v for k, v in total.items() if "k_fused<OpF32<0>, 1" in k or "k_links" in k or "k_pm_fill" in k}
