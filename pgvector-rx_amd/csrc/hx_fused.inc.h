@@ -165,13 +165,15 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const int sa_env = getenv("HX_SORTED_ARRAY") ? atoi(getenv("HX_SORTED_ARRAY")) : 0;
     const bool sa = sa_env && roomy == 1 && mode == 0 && dtype != HX_BIT && ef > 1 && ef <= 256 && !fused2_env_on();
     if (sa) clds = 0;                                            // no candidate heap
-    if (!sa) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
+    if (mode == 1) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
     if (dev && dev->d_wtab) clds = std::max<uint32_t>(clds, dev->wt_size);                     // so does the W table
     auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
-    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
+    const size_t waves_cap = 4u * (size_t)(mode == 2 ? FUSED_MINW_ITER : mode == 1 ? FUSED_MINW_INS : FUSED_MINW);   // register-file limit: launch_bounds waves per SIMD x 4 SIMDs
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max<size_t>(16, waves_cap), (160 * 1024) / (lds + 512)));
     { const char *pv = getenv(mode == 0 ? "HX_QUERY_PER_CU" : "HX_INSERT_PER_CU"); if (mode != 2 && pv && atoi(pv) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(pv)); }   // tuning knob
+    per_cu = std::min<uint32_t>(per_cu, FUSED_SLOTS_PER_CU);
     uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
     // k_fused2 (rows wider than 512 B, queries and inserts): one 1024-thread workgroup per CU, nc control waves + (16 - nc) stream waves
     const int fused2_env = fused2_env_on();   // experimental pooled-stream kernel: opt-in (measured slower than one wave per search so far)
@@ -216,7 +218,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         }
         HX_HIP(this, hipMemcpyAsync(mr.d_emask, it->emask, (size_t)it->n_elems * 2, hipMemcpyHostToDevice, stream));
     }
-    if (!mr.d_spill) HX_HIP(this, hipMalloc((void **)&mr.d_spill, (size_t)256 * 16 * FUSED_CCAP * 8));
+    if (!mr.d_spill) HX_HIP(this, hipMalloc((void **)&mr.d_spill, (size_t)256 * FUSED_SLOTS_PER_CU * FUSED_CCAP * 8));
     uint32_t *vis_ptr = nullptr; void *spill_ptr = mr.d_spill;
     if (roomy > 1) {   // a retry launch of a few overflowed tasks: private, larger tables sized for exactly this grid
         grid = std::min<uint32_t>(grid, 1024u);
@@ -228,7 +230,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     if (roomy == 1 && (uint64_t)grid * vis_words > mr.cap_vis) {
         if (mr.d_vis) (void)hipFree(mr.d_vis);
         mr.d_vis = nullptr; mr.cap_vis = 0;
-        const uint64_t n = (uint64_t)(mode == 2 ? grid : 256u * 16u) * vis_words;
+        const uint64_t n = (uint64_t)(mode == 2 ? grid : 256u * FUSED_SLOTS_PER_CU) * vis_words;
         HX_HIP(this, hipMalloc((void **)&mr.d_vis, n * 4));
         mr.cap_vis = n;
     }

@@ -12,6 +12,7 @@
 #ifndef FUSED_MINW
 #define FUSED_MINW 4
 #endif
+#define FUSED_SLOTS_PER_CU 24u     /* the per-wave spill areas and visited tables are sized for this many resident searches per CU */
 #ifndef FUSED_MINW_SA
 #define FUSED_MINW_SA 4             /* the sorted-array query kernel */
 #endif
