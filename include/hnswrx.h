@@ -33,7 +33,14 @@ extern "C" {
 #define HX_ABI_VERSION 1
 
 /* element type of the indexed column */
-enum hx_dtype { HX_F32 = 0 /* vector */, HX_F16 = 1 /* halfvec */, HX_BIT = 2 /* bit(n) */ };
+enum hx_dtype { HX_F32 = 0 /* vector */, HX_F16 = 1 /* halfvec */, HX_BIT = 2 /* bit(n) */, HX_SPARSE = 3 /* sparsevec */ };
+/* HX_SPARSE (src/types/sparsevec.rs): `dim` is the sparsevec's dimension count (<= 1e9) and a row is the fixed-size record
+ *   { int32 nnz; int32 pad[3]; int32 index[cap]; float value[cap]; } padded to a multiple of 16 bytes, cap = min(dim, 1000)
+ * (an indexed sparsevec holds at most 1000 non-zero elements), indices ascending and 0-based as in SparseVecHeader, unused slots zero (rows are
+ * compared bytewise for the duplicate test).  hx_row_bytes gives the record size.  Metrics: HX_L2SQ, HX_NEG_IP, HX_L1 -- the merge joins of
+ * sparse_l2_squared_distance / sparse_inner_product / sparsevec_l1_distance (sparsevec.rs:873-950, 1038-1088) with the reference's own f32
+ * accumulation order, one lane per pair; hx_normalize_rows = sparsevec_l2_normalize_raw (:1123-1178, zeros dropped).  The index runs on the
+ * lock-step driver for this type (the traversal and back-link kernels stream dense rows); no page image. */
 
 /* which opclass support FUNCTION 1 the index names (hnsw_constants.rs:12) */
 enum hx_metric {

@@ -23,6 +23,7 @@ pub const HX_ABI_VERSION: c_int = 1;
 pub const HX_F32: c_int = 0;
 pub const HX_F16: c_int = 1;
 pub const HX_BIT: c_int = 2;
+pub const HX_SPARSE: c_int = 3; // sparsevec as fixed-size records { nnz, pad[3], index[cap], value[cap] }, cap = min(dim, 1000): include/hnswrx.h
 // enum hx_metric: which opclass support FUNCTION 1 the index names (src/hnsw_constants.rs:12)
 pub const HX_L2SQ: c_int = 0;
 pub const HX_NEG_IP: c_int = 1;
@@ -172,6 +173,9 @@ pub fn engine_kind(distance_proc: &str) -> Option<(c_int, c_int, bool)> {
         "halfvec_l1_distance" => (HX_F16, HX_L1, false),
         "hamming_distance" => (HX_BIT, HX_HAMMING, false),
         "jaccard_distance" => (HX_BIT, HX_JACCARD, false),
+        "sparsevec_l2_squared_distance" => (HX_SPARSE, HX_L2SQ, false), // sparsevec.rs:1552-1582
+        "sparsevec_negative_inner_product" => (HX_SPARSE, HX_NEG_IP, false),
+        "sparsevec_l1_distance" => (HX_SPARSE, HX_L1, false),
         _ => return None,
     })
 }

@@ -39,7 +39,7 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
-enum { ORC_F32 = 0, ORC_F16 = 1, ORC_BIT = 2 };
+enum { ORC_F32 = 0, ORC_F16 = 1, ORC_BIT = 2, ORC_SPARSE = 3 };
 enum { ORC_L2SQ = 0, ORC_NEG_IP = 1, ORC_L1 = 2, ORC_HAMMING = 3, ORC_JACCARD = 4 };
 enum { ORC_ORDER_SEQ = 0, ORC_ORDER_W64 = 1, ORC_ORDER_VEC = 2 };
 enum { ORC_ITER_OFF = 0, ORC_ITER_RELAXED = 1, ORC_ITER_STRICT = 2 };
@@ -256,6 +256,72 @@ ORC_API double orc_jaccard(const uint8_t *a, const uint8_t *b, int nbytes)
 
 static inline int bit_nbytes(int dim) { return (dim + 7) / 8; }
 
+/* ---- sparsevec (src/types/sparsevec.rs) -------------------------------------------------------------------------
+ * A row is the fixed-size record the engine stores: { int32 nnz; int32 pad[3]; int32 index[cap]; float value[cap] } (+ padding to 16 bytes),
+ * cap = min(dim, 1000) (an indexed sparsevec has at most 1000 non-zero elements, sparsevec.rs hnsw support), indices
+ * ascending, unused slots zero.  The three loops below restate the reference's merge joins statement by statement:
+ * the f32 accumulation order is theirs. */
+#define ORC_SPARSE_MAX_NNZ 1000
+static inline int sparse_cap(int dim) { return dim < ORC_SPARSE_MAX_NNZ ? dim : ORC_SPARSE_MAX_NNZ; }
+static inline int sp_nnz(const void *r) { return *(const int32_t *)r; }
+static inline const int32_t *sp_idx(const void *r) { return (const int32_t *)((const uint8_t *)r + 16); }
+static inline const float *sp_val(const void *r, int cap) { return (const float *)((const uint8_t *)r + 16 + (size_t)cap * 4); }
+
+static float sparse_l2sq(const void *a, const void *b, int cap)      /* sparse_l2_squared_distance, sparsevec.rs:873-918 */
+{
+    const int32_t *ai_ = sp_idx(a), *bi_ = sp_idx(b); const float *ax = sp_val(a, cap), *bx = sp_val(b, cap);
+    const int an = sp_nnz(a), bn = sp_nnz(b);
+    float distance = 0.0f; int bpos = 0;
+    for (int i = 0; i < an; i++) {
+        const int32_t ai = ai_[i]; int32_t bi = -1;
+        for (int j = bpos; j < bn; j++) {
+            bi = bi_[j];
+            if (ai == bi) { float diff = ax[i] - bx[j]; distance += diff * diff; }
+            else if (ai > bi) distance += bx[j] * bx[j];
+            if (ai >= bi) bpos = j + 1;
+            if (bi >= ai) break;
+        }
+        if (ai != bi) distance += ax[i] * ax[i];
+    }
+    for (int j = bpos; j < bn; j++) distance += bx[j] * bx[j];
+    return distance;
+}
+static float sparse_ip(const void *a, const void *b, int cap)        /* sparse_inner_product, sparsevec.rs:921-950 */
+{
+    const int32_t *ai_ = sp_idx(a), *bi_ = sp_idx(b); const float *ax = sp_val(a, cap), *bx = sp_val(b, cap);
+    const int an = sp_nnz(a), bn = sp_nnz(b);
+    float distance = 0.0f; int bpos = 0;
+    for (int i = 0; i < an; i++) {
+        const int32_t ai = ai_[i];
+        for (int j = bpos; j < bn; j++) {
+            const int32_t bi = bi_[j];
+            if (ai == bi) distance += ax[i] * bx[j];
+            if (ai >= bi) bpos = j + 1;
+            if (bi >= ai) break;
+        }
+    }
+    return distance;
+}
+static float sparse_l1(const void *a, const void *b, int cap)        /* sparsevec_l1_distance, sparsevec.rs:1038-1088 */
+{
+    const int32_t *ai_ = sp_idx(a), *bi_ = sp_idx(b); const float *ax = sp_val(a, cap), *bx = sp_val(b, cap);
+    const int an = sp_nnz(a), bn = sp_nnz(b);
+    float distance = 0.0f; int bpos = 0;
+    for (int i = 0; i < an; i++) {
+        const int32_t ai = ai_[i]; int32_t bi = -1;
+        for (int j = bpos; j < bn; j++) {
+            bi = bi_[j];
+            if (ai == bi) distance += fabsf(ax[i] - bx[j]);
+            else if (ai > bi) distance += fabsf(bx[j]);
+            if (ai >= bi) bpos = j + 1;
+            if (bi >= ai) break;
+        }
+        if (ai != bi) distance += fabsf(ax[i]);
+    }
+    for (int j = bpos; j < bn; j++) distance += fabsf(bx[j]);
+    return distance;
+}
+
 /*
  * The opclass support function 1 ("distance proc"), f64 result:
  *   vector_l2_squared_distance vector.rs:598-607, vector_negative_inner_product :624-633,
@@ -263,6 +329,15 @@ static inline int bit_nbytes(int dim) { return (dim + 7) / 8; }
  */
 ORC_API double orc_distance(int dtype, int metric, int dim, const void *a, const void *b, int order)
 {
+    if (dtype == ORC_SPARSE) {                       /* sparsevec_l2_squared_distance / _negative_inner_product / _l1_distance, sparsevec.rs:970-1003, 1038 */
+        const int cap = sparse_cap(dim);
+        switch (metric) {
+        case ORC_L2SQ:   return (double)sparse_l2sq(a, b, cap);
+        case ORC_NEG_IP: return -(double)sparse_ip(a, b, cap);
+        case ORC_L1:     return (double)sparse_l1(a, b, cap);
+        }
+        return NAN;
+    }
     switch (metric) {
     case ORC_L2SQ:   return (double)acc_f(T_L2, dtype, dim, a, b, order);
     case ORC_NEG_IP: return -(double)acc_f(T_IP, dtype, dim, a, b, order);
@@ -274,12 +349,23 @@ ORC_API double orc_distance(int dtype, int metric, int dim, const void *a, const
 }
 
 /* The SQL-level helpers that exist only for the known-answer tests. */
-ORC_API double orc_l2_distance(int dtype, int dim, const void *a, const void *b)   /* vector.rs:586-593 */
-{ return sqrt((double)acc_seq(T_L2, dtype, dim, a, b)); }
-ORC_API double orc_inner_product(int dtype, int dim, const void *a, const void *b) /* vector.rs:612-619 */
-{ return (double)acc_seq(T_IP, dtype, dim, a, b); }
+ORC_API double orc_l2_distance(int dtype, int dim, const void *a, const void *b)   /* vector.rs:586-593; sparsevec.rs:953-966 */
+{ return dtype == ORC_SPARSE ? sqrt((double)sparse_l2sq(a, b, sparse_cap(dim))) : sqrt((double)acc_seq(T_L2, dtype, dim, a, b)); }
+ORC_API double orc_inner_product(int dtype, int dim, const void *a, const void *b) /* vector.rs:612-619; sparsevec.rs:980-991 */
+{ return dtype == ORC_SPARSE ? (double)sparse_ip(a, b, sparse_cap(dim)) : (double)acc_seq(T_IP, dtype, dim, a, b); }
 ORC_API double orc_cosine_distance(int dtype, int dim, const void *a, const void *b)
 {   /* vector.rs:541-556 + :638-647 */
+    if (dtype == ORC_SPARSE) {                       /* sparsevec_cosine_distance, sparsevec.rs:1005-1036: f32 norms over the stored values */
+        const int cap = sparse_cap(dim);
+        const float *ax = sp_val(a, cap), *bx = sp_val(b, cap);
+        double sim = (double)sparse_ip(a, b, cap);
+        float na = 0.0f, nb = 0.0f;
+        for (int i = 0; i < sp_nnz(a); i++) na += ax[i] * ax[i];
+        for (int i = 0; i < sp_nnz(b); i++) nb += bx[i] * bx[i];
+        sim /= sqrt((double)na * (double)nb);
+        if (sim < -1.0) sim = -1.0; if (sim > 1.0) sim = 1.0;
+        return 1.0 - sim;
+    }
     float s = 0.0f, na = 0.0f, nb = 0.0f;
     for (int i = 0; i < dim; i++) {
         float ai = elem_f32(a, dtype, i), bi = elem_f32(b, dtype, i);
@@ -293,6 +379,11 @@ ORC_API double orc_cosine_distance(int dtype, int dim, const void *a, const void
 /* vector_norm vector.rs:672-683 (f64 accumulator) */
 ORC_API double orc_norm(int dtype, int dim, const void *a)
 {
+    if (dtype == ORC_SPARSE) {                       /* sparsevec_l2_norm: f64 accumulator over the stored values */
+        const float *x = sp_val(a, sparse_cap(dim)); double n = 0.0;
+        for (int i = 0; i < sp_nnz(a); i++) n += (double)x[i] * (double)x[i];
+        return sqrt(n);
+    }
     double n = 0.0;
     for (int i = 0; i < dim; i++) { double v = (double)elem_f32(a, dtype, i); n += v * v; }
     return sqrt(n);
@@ -301,6 +392,19 @@ ORC_API double orc_norm(int dtype, int dim, const void *a)
 /* l2_normalize_raw vector.rs:106-126 / halfvec.rs:204-233.  Returns the norm; out is zero-filled when norm==0. */
 ORC_API double orc_l2_normalize(int dtype, int dim, const void *in, void *out)
 {
+    if (dtype == ORC_SPARSE) {                       /* sparsevec_l2_normalize_raw, sparsevec.rs:1123-1178: f64 norm, zeros dropped */
+        const int cap = sparse_cap(dim), nnz = sp_nnz(in);
+        const float *x = sp_val(in, cap); const int32_t *xi = sp_idx(in);
+        double norm = 0.0;
+        for (int i = 0; i < nnz; i++) { double v = (double)x[i]; norm += v * v; }
+        norm = sqrt(norm);
+        memset(out, 0, (16 + (size_t)cap * 8 + 15) & ~(size_t)15);
+        int32_t *oi = (int32_t *)((uint8_t *)out + 16); float *ov = (float *)((uint8_t *)out + 16 + (size_t)cap * 4);
+        int k = 0;
+        if (norm > 0.0) for (int i = 0; i < nnz; i++) { float v = (float)((double)x[i] / norm); if (v != 0.0f) { oi[k] = xi[i]; ov[k] = v; k++; } }
+        *(int32_t *)out = k;
+        return norm;
+    }
     double norm = orc_norm(dtype, dim, in);
     if (dtype == ORC_F32) {
         float *o = out; const float *x = in;
@@ -441,6 +545,7 @@ ORC_API int orc_level_from_uniform(double u, int m)
 
 ORC_API size_t orc_row_bytes(int dtype, int dim)
 {
+    if (dtype == ORC_SPARSE) return (16 + (size_t)sparse_cap(dim) * 8 + 15) & ~(size_t)15;
     return dtype == ORC_F32 ? (size_t)dim * 4 : dtype == ORC_F16 ? (size_t)dim * 2 : (size_t)bit_nbytes(dim);
 }
 

@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ORC_LIB") or os.path.join(HERE, "_build", "liborc.so")   # ORC_LIB: e.g. an ASan/UBSan build of the oracle
 
-F32, F16, BIT = 0, 1, 2
+F32, F16, BIT, SPARSE = 0, 1, 2, 3   # SPARSE rows are the engine's fixed-size sparsevec records (uint8; pgvector-rx_amd/binding.py: pack_sparse)
 L2SQ, NEG_IP, L1, HAMMING, JACCARD = 0, 1, 2, 3, 4
 SEQ, W64, VEC = 0, 1, 2     # VEC: reassociated + compiler-vectorised CPU variant (bench baseline only, not the reference's arithmetic)
 ITER_OFF, ITER_RELAXED, ITER_STRICT = 0, 1, 2
@@ -93,7 +93,7 @@ def lib():
     return _lib
 
 
-_NP = {F32: np.float32, F16: np.uint16, BIT: np.uint8}
+_NP = {F32: np.float32, F16: np.uint16, BIT: np.uint8, SPARSE: np.uint8}
 
 
 def as_rows(dtype, a):
@@ -136,6 +136,25 @@ def l2_normalize(dtype, dim, a):
     out = np.zeros_like(a)
     norm = lib().orc_l2_normalize(dtype, dim, _p(a), _p(out))
     return out, norm
+
+
+def pack_sparse(dim, idx, val):
+    """One sparsevec as the fixed-size record of ORC_SPARSE rows: {int32 nnz; int32 pad[3]; int32 index[cap]; float32 value[cap]}, cap = min(dim, 1000)."""
+    cap = min(dim, 1000)
+    rb = (16 + 8 * cap + 15) & ~15
+    idx, val = np.asarray(idx, np.int32), np.asarray(val, np.float32)
+    out = np.zeros(rb, np.uint8)
+    out[0:4] = np.array([len(idx)], np.int32).view(np.uint8)
+    out[16:16 + 4 * len(idx)] = idx.view(np.uint8)
+    out[16 + 4 * cap:16 + 4 * cap + 4 * len(val)] = val.view(np.uint8)
+    return out
+
+
+def sparse_from_dense(v):
+    """A dense literal -> the sparsevec the reference's vector::sparsevec cast stores (non-zero elements only)."""
+    v = np.asarray(v, np.float32)
+    nz = np.nonzero(v)[0]
+    return pack_sparse(len(v), nz, v[nz])
 
 
 def pack_bits(bitstring):

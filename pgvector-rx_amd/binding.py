@@ -6,10 +6,31 @@ import numpy as np
 
 from . import build as _build
 
-F32, F16, BIT = 0, 1, 2
+F32, F16, BIT, SPARSE = 0, 1, 2, 3
 L2SQ, NEG_IP, L1, HAMMING, JACCARD = 0, 1, 2, 3, 4
 QUERY_SLOT = 0x80000000
-_NP = {F32: np.float32, F16: np.uint16, BIT: np.uint8}
+_NP = {F32: np.float32, F16: np.uint16, BIT: np.uint8, SPARSE: np.uint8}
+SPARSE_MAX_NNZ = 1000
+
+
+def sparse_record_bytes(dim):
+    return (16 + 8 * min(dim, SPARSE_MAX_NNZ) + 15) & ~15
+
+
+def pack_sparse(dim, rows):
+    """rows: iterable of (indices, values) -- ascending 0-based indices, at most 1000 of them -> uint8[n, record] in the engine's HX_SPARSE
+    record layout {int32 nnz; int32 pad[3]; int32 index[cap]; float32 value[cap]} (include/hnswrx.h), unused slots zero."""
+    cap, rb = min(dim, SPARSE_MAX_NNZ), sparse_record_bytes(dim)
+    rows = list(rows)
+    out = np.zeros((len(rows), rb), np.uint8)
+    for r, (idx, val) in enumerate(rows):
+        idx, val = np.asarray(idx, np.int32), np.asarray(val, np.float32)
+        k = len(idx)
+        assert k == len(val) and k <= cap and (k < 2 or np.all(np.diff(idx) > 0)) and (k == 0 or (idx[0] >= 0 and idx[-1] < dim))
+        out[r, 0:4] = np.array([k], np.int32).view(np.uint8)
+        out[r, 16:16 + 4 * k] = idx.view(np.uint8)
+        out[r, 16 + 4 * cap:16 + 4 * cap + 4 * k] = val.view(np.uint8)
+    return out
 
 _lib = None
 

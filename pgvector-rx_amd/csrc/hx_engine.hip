@@ -360,6 +360,12 @@ int hx_engine::run_round()
     if (n_mf && (dtype != HX_F16 || metric != HX_NEG_IP)) return fail(HX_E_ARG, "the MFMA pair path serves halfvec inner product");
     if (!do_dist && n_wgs == 0 && n_mf == 0) return HX_OK;
     HX_HIP(this, hipMemcpyAsync(c.d_req, c.h_req, c.req_bytes, hipMemcpyHostToDevice, stream));
+    if (dtype == HX_SPARSE && n_mf) return fail(HX_E_ARG, "the MFMA pair path serves halfvec inner product");
+    if (do_dist && dtype == HX_SPARSE) {                        // sparsevec: the merge-join kernels of hx_sparse.hip on the same request arrays
+        if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
+        HX_HIP(this, hx_launch_sparse_dist(this, r.n_dgroups));
+        if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
+    } else
     if (do_dist) {
         if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
 #define F32C(K) launch_dist<OpF32<K>>(this, r.n_dgroups)
@@ -370,6 +376,11 @@ int hx_engine::run_round()
         HX_HIP(this, hipGetLastError());
         if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
     }
+    if (n_wgs && dtype == HX_SPARSE) {
+        if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+        HX_HIP(this, hx_launch_sparse_pairs(this, n_wgs));
+        if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    } else
     if (n_wgs) {
         if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
         hipError_t ls = hipSuccess;
@@ -414,12 +425,13 @@ int hx_create(int device, int dtype, int metric, int dim, uint64_t capacity_rows
 {
     if (!out) return create_fail(HX_E_ARG, "out is NULL");
     *out = nullptr;
-    if (dtype < HX_F32 || dtype > HX_BIT) return create_fail(HX_E_ARG, "unknown dtype");
+    if (dtype < HX_F32 || dtype > HX_SPARSE) return create_fail(HX_E_ARG, "unknown dtype");
     const bool bit_metric = metric == HX_HAMMING || metric == HX_JACCARD;
     if (metric < HX_L2SQ || metric > HX_JACCARD || bit_metric != (dtype == HX_BIT))
         return create_fail(HX_E_ARG, "metric does not belong to this dtype's operator classes");
-    // index dimension limits: hnsw_constants.rs:4 (vector 2000), halfvec.rs:876 (2x), bitvec.rs:184 (32x)
-    const int max_dim = dtype == HX_F32 ? 2000 : dtype == HX_F16 ? 4000 : 64000;
+    // index dimension limits: hnsw_constants.rs:4 (vector 2000), halfvec.rs:876 (2x), bitvec.rs:184 (32x); sparsevec: SPARSEVEC_MAX_DIM 1e9,
+    // at most 1000 non-zero elements in an indexed value
+    const int max_dim = dtype == HX_F32 ? 2000 : dtype == HX_F16 ? 4000 : dtype == HX_BIT ? 64000 : 1000000000;
     if (dim < 1) return create_fail(HX_E_DIM, "column must have at least 1 dimension");
     if (dim > max_dim) return create_fail(HX_E_DIM, "column cannot have more than " + std::to_string(max_dim) + " dimensions for hnsw index");
     int ndev = 0;
@@ -429,7 +441,8 @@ int hx_create(int device, int dtype, int metric, int dim, uint64_t capacity_rows
     hx_engine *e = new (std::nothrow) hx_engine();
     if (!e) return create_fail(HX_E_NOMEM, "out of host memory");
     e->device = device; e->dtype = dtype; e->metric = metric; e->dim = dim;
-    e->row_bytes = dtype == HX_F32 ? (uint64_t)dim * 4 : dtype == HX_F16 ? (uint64_t)dim * 2 : (uint64_t)(dim + 7) / 8;
+    e->row_bytes = dtype == HX_F32 ? (uint64_t)dim * 4 : dtype == HX_F16 ? (uint64_t)dim * 2 : dtype == HX_BIT ? (uint64_t)(dim + 7) / 8
+                 : (16 + 8 * (uint64_t)std::min(dim, HX_SPARSE_MAX_NNZ) + 15) & ~(uint64_t)15;      // sparsevec record (include/hnswrx.h)
     e->pitch = (e->row_bytes + 15) & ~(uint64_t)15;
     e->capacity = capacity_rows ? capacity_rows : 1024;
     hipError_t s;
@@ -527,7 +540,8 @@ static int normalize_region(hx_engine *e, uint8_t *base, uint64_t n, double *nor
     double *d_norms = nullptr;
     HX_HIP(e, hipMalloc((void **)&d_norms, n * sizeof(double)));
     const uint32_t blk = 64, grid = (uint32_t)((n + blk - 1) / blk);
-    if (e->dtype == HX_F32) hipLaunchKernelGGL((k_normalize<HX_F32>), dim3(grid), dim3(blk), 0, e->stream, base, (uint32_t)e->pitch, e->dim, n, d_norms);
+    if (e->dtype == HX_SPARSE) (void)hx_launch_sparse_normalize(e, base, n, d_norms);
+    else if (e->dtype == HX_F32) hipLaunchKernelGGL((k_normalize<HX_F32>), dim3(grid), dim3(blk), 0, e->stream, base, (uint32_t)e->pitch, e->dim, n, d_norms);
     else hipLaunchKernelGGL((k_normalize<HX_F16>), dim3(grid), dim3(blk), 0, e->stream, base, (uint32_t)e->pitch, e->dim, n, d_norms);
     hipError_t s = hipGetLastError();
     if (s == hipSuccess && norms_host) s = hipMemcpyAsync(norms_host, d_norms, n * sizeof(double), hipMemcpyDeviceToHost, e->stream);

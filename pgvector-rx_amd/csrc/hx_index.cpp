@@ -787,7 +787,7 @@ struct hx_index {
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
 
-    bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192; }
+    bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192 && e->dtype != HX_SPARSE; }   // sparsevec: lock-step driver (merge-join kernels)
     // device-resident batches (hx_batch.hip): the traversal kernel and the back-link kernels both serve this m
     bool dbatch_ok() const { static const bool off = getenv("HX_DEVICE_BATCH") && atoi(getenv("HX_DEVICE_BATCH")) == 0; return !off && fused_ok() && 2 * g.m <= 64; }
     void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
@@ -2228,6 +2228,7 @@ int hx_index_serialize_pages(const hx_index *cix, uint8_t *pages_out, uint64_t c
 {
     if (!cix || !n_pages_out) return HX_E_ARG;
     hx_index *ix = const_cast<hx_index *>(cix);
+    if (ix->e->dtype == HX_SPARSE) return ix->fail(HX_E_ARG, "no page image for sparsevec (its varlena is variable-length; the engine holds fixed-size records)");
     { int rc0 = ix->ensure_host_lists(); if (rc0) return rc0; }
     const Graph &g = ix->g;
     const hx_engine *e = ix->e;
@@ -2343,6 +2344,7 @@ int hx_index_load_pages(hx_index *ix, const uint8_t *pages, uint64_t n_pages, ui
 {
     if (!ix || !pages || !n_elems_out) return HX_E_ARG;
     Graph &g = ix->g; hx_engine *e = ix->e;
+    if (e->dtype == HX_SPARSE) return ix->fail(HX_E_ARG, "no page image for sparsevec");
     if (g.size() != 0 || hx_num_rows(e) != 0) return ix->fail(HX_E_STATE, "hx_index_load_pages needs an empty index on an empty engine");
     if (n_pages < 2 || n_pages > 0xFFFFFFFEull) return ix->fail(HX_E_ARG, "page image too short");
     const uint8_t *meta = pages + PG_PAGE_HDR;

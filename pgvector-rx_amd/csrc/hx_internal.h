@@ -150,6 +150,11 @@ struct hx_engine {
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 
+// hx_sparse.hip: the sparsevec kernels (same request arrays as K1 / K2)
+#define HX_SPARSE_MAX_NNZ 1000
+hipError_t hx_launch_sparse_dist(hx_engine *e, uint32_t n_groups);
+hipError_t hx_launch_sparse_pairs(hx_engine *e, uint32_t n_wgs);
+hipError_t hx_launch_sparse_normalize(hx_engine *e, uint8_t *base, uint64_t n, double *d_norms);
 hipError_t hx_launch_pair_mfma(hx_engine *e, uint32_t n_groups, const uint32_t *d_glist);
 
 #define HX_HIP(e, call)                                                                             \

@@ -10,7 +10,7 @@ import pytest
 from oracle import orc
 
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
-TYPE = {"vector": orc.F32, "halfvec": orc.F16, "bit": orc.BIT}
+TYPE = {"vector": orc.F32, "halfvec": orc.F16, "bit": orc.BIT, "sparsevec": orc.SPARSE}
 
 
 def enc(tname, v):
@@ -19,6 +19,8 @@ def enc(tname, v):
         return np.asarray(v, np.float32), len(v)
     if tname == "halfvec":
         return np.array([orc.lib().orc_f32_to_half(float(x)) for x in v], np.uint16), len(v)
+    if tname == "sparsevec":                      # written densely in the fixture: '{1:3,2:4}/3' = [3, 4, 0]; sparsevec.rs:217-330 keeps the non-zeros
+        return orc.sparse_from_dense(v), len(v)
     return orc.pack_bits(v), len(v)
 
 
