@@ -153,7 +153,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     // (the largest heap seen on 1M x 768 builds was 1552 entries at ef = 200); beyond FUSED_CCAP a task reports
     // FS_OVERFLOW and is re-run by the lock-step path
     const size_t nch_ = (pitch + 1023) / 1024;
-    if (roomy < 1 || mode == 2) roomy = 1;
+    if (roomy < 1) roomy = 1;
     const uint32_t ccap = FUSED_CCAP * roomy;
     uint32_t clds = mode == 1 ? 600u : 512u;     // insert: 600 entries measured +8 % over 1024 (13 instead of 10 searches per CU at ef_construction 200)
     uint32_t disc_lds = mode == 2 ? 512u : 0u;
@@ -190,14 +190,16 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const uint64_t vis_need = ((uint64_t)ef * 2 * mr.m * 2 + 1024) * (n_rows >= 4000000ull ? 2 : 1);
     uint64_t vis_words = 4096; while (vis_words < vis_need) vis_words <<= 1;
     { const char *vv = getenv("HX_VIS_SHIFT"); if (vv && mode != 2) { const int sh = atoi(vv); if (sh < 0) vis_words >>= -sh; else vis_words <<= sh; if (vis_words < 4096) vis_words = 4096; } }   // tuning knob
-    vis_words *= roomy;
+    if (mode != 2) vis_words *= roomy;
     uint64_t disc_stride = 0;
     if (mode == 2) {
         // an iterative scan keeps its visited set and `discarded` heap across resumes: sized for max_scan_tuples (a query that
-        // outgrows them reports FS_OVERFLOW and is re-run by the lock-step path); fewer resident workgroups bound the footprint
+        // outgrows them reports FS_OVERFLOW, is retried with `roomy` x the tables and only then re-run by the lock-step path); fewer resident
+        // workgroups bound the footprint
         const uint64_t mt = (uint64_t)std::min<long long>(std::max<long long>(it->max_tuples, 1), 1 << 20);
-        disc_stride = std::max<uint64_t>(4 * mt, 16384);
+        disc_stride = std::max<uint64_t>(4 * mt, 16384) * roomy;
         while (vis_words < 8 * mt + 4096) vis_words <<= 1;
+        vis_words *= roomy;
         { const char *vv = getenv("HX_ITER_VIS_SHIFT"); if (vv) { const int sh = atoi(vv); if (sh < 0) vis_words >>= -sh; else vis_words <<= sh; if (vis_words < 8192) vis_words = 8192; } }   // tuning knob
         // at most ~12 GB of per-query state: a huge max_scan_tuples gets fewer resident queries, never less than one per CU pair
         const uint64_t per_wg = disc_stride * 8 + vis_words * 4;

@@ -2115,16 +2115,29 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
                                    oids.data(), od.data(), ocnt.data(), status.data(), cnts, &it))) return ix->fail(rc, ix->e->err);
         ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ix->counters[4] += cnts[0];
-        for (uint32_t q = 0; q < nq; q++) {
-            if (status[q] != 0) { todo.push_back(q); continue; }
-            const uint32_t c = std::min(ocnt[q], limit);
+        auto take = [&](uint32_t q, size_t src, const uint32_t *cn, const uint32_t *ids, const uint32_t *tix, const float *dd) {
+            const uint32_t c = std::min(cn[src], limit);
             for (uint32_t i = 0; i < c; i++) {
-                const uint32_t el = oids[(size_t)q * limit + i];
-                tids_out[(size_t)q * limit + i] = g.tids[el][otix[(size_t)q * limit + i]];
-                if (dist_out) dist_out[(size_t)q * limit + i] = od[(size_t)q * limit + i];
+                const uint32_t el = ids[src * limit + i];
+                tids_out[(size_t)q * limit + i] = g.tids[el][tix[src * limit + i]];
+                if (dist_out) dist_out[(size_t)q * limit + i] = dd[src * limit + i];
                 if (elems_out) elems_out[(size_t)q * limit + i] = el;
             }
             counts_out[q] = c;
+        };
+        std::vector<uint32_t> again;                             // scans that outgrew their visited table / discarded heap: once more on the device, 8x the room
+        for (uint32_t q = 0; q < nq; q++) {
+            if (status[q] == 1) again.push_back(q); else if (status[q] != 0) todo.push_back(q); else take(q, q, ocnt.data(), oids.data(), otix.data(), od.data());
+        }
+        if (!again.empty()) {
+            const uint32_t na = (uint32_t)again.size();
+            std::vector<uint32_t> q2(na), st2(na), c2(na), i2((size_t)na * limit), x2((size_t)na * limit); std::vector<float> d2((size_t)na * limit);
+            for (uint32_t k = 0; k < na; k++) q2[k] = HX_QUERY_SLOT | again[k];
+            HxFusedIter it2 = it; it2.out_tix = x2.data();
+            if ((rc = ix->e->fused_run(2, na, q2.data(), nullptr, ef_search, limit, (uint32_t)g.entry, g.level[g.entry],
+                                       i2.data(), d2.data(), c2.data(), st2.data(), cnts, &it2, nullptr, 8))) return ix->fail(rc, ix->e->err);
+            ix->counters[4] += cnts[0];
+            for (uint32_t k = 0; k < na; k++) { if (st2[k] != 0) todo.push_back(again[k]); else take(again[k], k, c2.data(), i2.data(), x2.data(), d2.data()); }
         }
         ix->fused_tasks += nq; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;

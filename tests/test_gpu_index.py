@@ -566,6 +566,38 @@ def test_iterative_scan_on_device_equals_lockstep_and_oracle(dt, metric, dim, n,
 
 
 @pytest.mark.gpu
+def test_iterative_scan_that_outgrows_its_tables_is_retried_on_the_device():
+    """An iterative scan whose visited table fills up reports FS_OVERFLOW; it is run again on the device with 8x the tables before the lock-step
+    driver is considered (a deep scan there costs thousands of host round trips).  HX_ITER_VIS_SHIFT=-5 makes the first tables 32x too small."""
+    import os
+    rng = np.random.default_rng(19)
+    n, dim, m, efc = 6000, 8, 8, 32
+    rows = make_rows(hx.F32, n, dim, rng)
+    levels = hx.draw_levels(n, m, seed=19)
+    e, ix, _, o, _ = build_both(hx.F32, hx.L2SQ, dim, rows, levels, m, efc, 64)
+    nq, efs, limit = 30, 20, 9
+    qs = make_rows(hx.F32, nq, dim, rng)
+    e.set_queries(qs)
+    passes = (np.arange(n) % 700 == 0).astype(np.uint8)
+    ref = ix.search_iterative(nq, efs, 1, 20000, limit, passes)
+    os.environ["HX_ITER_VIS_SHIFT"] = "-5"
+    try:
+        before = ix.fused_stats()
+        got = ix.search_iterative(nq, efs, 1, 20000, limit, passes)
+        after = ix.fused_stats()
+    finally:
+        del os.environ["HX_ITER_VIS_SHIFT"]
+    assert after["redone"] == before["redone"]                       # nothing reached the lock-step driver
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    for q in range(0, nq, 3):
+        want = [t for t, x, _ in o.scan(qs[q], ef_search=efs, iterative=orc.ITER_RELAXED, max_scan_tuples=20000) if passes[t]][:limit]
+        assert got[0][q, :got[2][q]].tolist() == want
+    ix.close()
+    e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt,dim", [(hx.F32, 24), (hx.F16, 40)])
 def test_hub_lists_inner_product_long_back_link_chains(dt, dim):
     """Inner product on rows of very different norms: a few high-norm rows are everybody's neighbour, so single lists receive

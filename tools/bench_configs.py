@@ -47,7 +47,7 @@ def clustered(g, n, dim, centers, sigma):
 def run(name, n, data="baseline"):
     g = torch.Generator(device=DEV)
     g.manual_seed(21)
-    k, nq, batch = 10, 10_000, 8192
+    k, nq, batch = 10, 10_000, int(os.environ.get("HX_BATCH_CAP", "32768"))   # the bench's insert batch cap (a batch is also at most 1/8 of the graph)
     iterative = None
     if name == "c1":
         n = n or 10_000
