@@ -180,7 +180,7 @@ def test_iterative_scan_matches_oracle(mode):
 
 
 METRIC = {"l2": hx.L2SQ, "ip": hx.NEG_IP, "cosine": hx.NEG_IP, "l1": hx.L1, "hamming": hx.HAMMING, "jaccard": hx.JACCARD}
-TYPE = {"vector": hx.F32, "halfvec": hx.F16, "bit": hx.BIT}
+TYPE = {"vector": hx.F32, "halfvec": hx.F16, "bit": hx.BIT, "sparsevec": hx.SPARSE}
 
 
 def enc(tname, v):
@@ -188,6 +188,8 @@ def enc(tname, v):
         return np.asarray(v, np.float32), len(v)
     if tname == "halfvec":
         return np.asarray(v, np.float32).astype(np.float16).view(np.uint16), len(v)
+    if tname == "sparsevec":                      # the fixture writes '{1:3,2:4}/3' densely as [3, 4, 0]
+        return orc.sparse_from_dense(v), len(v)
     return orc.pack_bits(v), len(v)
 
 
