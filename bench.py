@@ -224,7 +224,7 @@ def run(a, json_fd):
 
     # ---- build (timed once; barrier + sync on both sides; max over ranks) ----
     # a batch is shared by the ranks, so its cap grows with them: every GPU keeps a full launch of searches per batch
-    eff_batch = min(a.batch * world, 65536)
+    eff_batch = min(a.batch * world, 262144)
     dist_stages = None
     barrier()
     t0 = time.perf_counter()

@@ -125,14 +125,31 @@ struct VisitedSet {
 // ------------------------------------------------------------------------------------------------
 constexpr int HEAPTIDS = 10;   // hnsw_constants.rs:85
 
+// Allocator whose value-less construct() default-initialises: growing the list / TID arrays by a batch then touches no memory (a list's slots beyond
+// its count and a TID array's beyond ntids are never read), so a 10M-row build does not page in and zero 3 GB of host arrays it may never look at --
+// during device batches the lists live in the mirror (the replicated O(batch) host work is what bounds the multi-GPU speed-up).
+template <class T> struct NoInitAlloc {
+    using value_type = T;
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { ::operator delete(p); }
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const NoInitAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const NoInitAlloc<U> &) const { return false; }
+};
+
 struct Graph {
     int m = 16;
     std::vector<int32_t> level;              // < 0: tombstoned duplicate
-    std::vector<uint16_t> n0_cnt; std::vector<Cand> n0;             // layer 0: stride 2m
+    std::vector<uint16_t> n0_cnt; std::vector<Cand, NoInitAlloc<Cand>> n0;   // layer 0: stride 2m
     std::vector<uint64_t> up_off;                                    // first slot of layers 1..level in `up`
-    std::vector<Cand> up; std::vector<uint16_t> up_cnt;              // up: stride m per layer; up_cnt per (elem, layer)
+    std::vector<Cand, NoInitAlloc<Cand>> up; std::vector<uint16_t> up_cnt;   // up: stride m per layer; up_cnt per (elem, layer)
     std::vector<uint64_t> upc_off;
-    std::vector<std::array<int64_t, HEAPTIDS>> tids; std::vector<uint8_t> ntids;
+    std::vector<std::array<int64_t, HEAPTIDS>, NoInitAlloc<std::array<int64_t, HEAPTIDS>>> tids; std::vector<uint8_t> ntids;
     std::vector<uint8_t> deleted;           // HnswElementTupleData.deleted (types/hnsw.rs:112-137): set by vacuum's mark_deleted
     int64_t entry = -1;
 
