@@ -286,6 +286,12 @@ int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int
                               uint32_t limit, const uint8_t *filter_pass, uint64_t n_filter,
                               int64_t *tids_out, float *dist_out, uint32_t *counts_out);
 
+/* One scan with a NULL order-by value (`ORDER BY val <-> NULL`; scan.rs:186-187: every element gets distance 0.0, the distance procedure is
+ * never called).  Pure graph traversal on the host -- there is nothing to compute -- in the order Rust's BinaryHeap gives equal keys.
+ * mode 0: plain scan (k = limit), 1 / 2: iterative as above.  tids_out / elems_out (may be NULL): `limit` entries; *count_out = tuples returned. */
+int hx_index_search_null(hx_index *ix, uint32_t ef_search, int mode, int64_t max_scan_tuples, uint32_t limit,
+                         const uint8_t *filter_pass, uint64_t n_filter, int64_t *tids_out, uint32_t *elems_out, uint32_t *count_out);
+
 /* ---- graph -> PostgreSQL index pages -----------------------------------------
  * Serialises the built graph as the byte image of the HNSW relation fork, exactly as ambuild flushes it:
  * create_meta_page + create_graph_pages + write_neighbor_tuples + update_meta_page (src/index/build.rs:545-821)

@@ -130,6 +130,9 @@ extern "C" {
     pub fn hx_index_search_iterative(ix: *mut hx_index, nq: u32, ef_search: u32, mode: c_int, max_scan_tuples: i64, limit: u32,
                                      filter_pass: *const u8, n_filter: u64, tids_out: *mut i64, dist_out: *mut f32,
                                      counts_out: *mut u32) -> c_int;
+    /// `ORDER BY val <-> NULL` (scan.rs:186-187): traversal with every distance 0.0, no kernel involved.
+    pub fn hx_index_search_null(ix: *mut hx_index, ef_search: u32, mode: c_int, max_scan_tuples: i64, limit: u32, filter_pass: *const u8,
+                                n_filter: u64, tids_out: *mut i64, elems_out: *mut u32, count_out: *mut u32) -> c_int;
     // PostgreSQL page image <-> engine
     pub fn hx_index_serialize_pages(ix: *const hx_index, pages_out: *mut u8, cap_pages: u64, n_pages_out: *mut u64,
                                     elem_blkno_out: *mut u32, elem_offno_out: *mut u16) -> c_int;

@@ -124,6 +124,7 @@ def lib():
         "hx_index_fused_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
         "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
+        "hx_index_search_null": (i32, [vp, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
         "hx_index_serialize_pages": (i32, [vp, vp, u64, C.POINTER(u64), vp, vp]),
         "hx_index_load_pages": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
     }
@@ -516,6 +517,15 @@ class Index:
         cnt = np.zeros(nq, np.uint32)
         self._ck(lib().hx_index_search(self.h, nq, ef_search, k, _p(tids), _p(d), _p(el), _p(cnt)))
         return tids, d, el, cnt
+
+    def search_null(self, ef_search, limit, mode=0, max_scan_tuples=20000, filter_pass=None):
+        """ORDER BY val <-> NULL (scan.rs:186-187): (tids, elems) of the traversal with every distance 0.0."""
+        tids = np.full(limit, -1, np.int64)
+        el = np.zeros(limit, np.uint32)
+        cnt = C.c_uint32()
+        f = None if filter_pass is None else np.ascontiguousarray(filter_pass, np.uint8)
+        self._ck(lib().hx_index_search_null(self.h, ef_search, mode, max_scan_tuples, limit, _p(f), 0 if f is None else len(f), _p(tids), _p(el), C.byref(cnt)))
+        return tids[:cnt.value], el[:cnt.value]
 
     def search_iterative(self, nq, ef_search, mode, max_scan_tuples, limit, filter_pass=None):
         tids = np.full((nq, limit), -1, np.int64)

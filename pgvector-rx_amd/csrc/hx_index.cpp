@@ -2205,6 +2205,29 @@ int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int
     return search_impl(ix, nq, ef_search, mode, max_scan_tuples, limit, filter_pass, n_filter, tids_out, dist_out, nullptr, counts_out);
 }
 
+// A NULL order-by value (`ORDER BY val <-> NULL`): load_element reports distance 0.0 for every element without calling the distance procedure
+// (scan.rs:186-187), so the scan is graph traversal only -- which elements it reaches, and in which order, follows from Rust's BinaryHeap on equal
+// keys.  No arithmetic, hence no kernel: the lock-step scan task runs on the host with zeros for every distance it asks for.
+int hx_index_search_null(hx_index *ix, uint32_t ef_search, int mode, int64_t max_scan_tuples, uint32_t limit,
+                         const uint8_t *filter_pass, uint64_t n_filter, int64_t *tids_out, uint32_t *elems_out, uint32_t *count_out)
+{
+    if (!ix || !tids_out || !count_out) return HX_E_ARG;
+    if (mode < 0 || mode > 2) return ix->fail(HX_E_ARG, "mode must be 0 (off), 1 (relaxed_order) or 2 (strict_order)");
+    if (ef_search < 1 || ef_search > 1000) return ix->fail(HX_E_ARG, "hnsw.ef_search must be between 1 and 1000");
+    if (mode != 0 && max_scan_tuples < 1) return ix->fail(HX_E_ARG, "hnsw.max_scan_tuples must be at least 1");
+    { int rc0 = ix->ensure_host_lists(); if (rc0) return rc0; }
+    QueryTask t;
+    t.g = &ix->g; t.slot = 0; t.ef_search = ef_search; t.mode = mode; t.max_scan_tuples = max_scan_tuples; t.limit = limit;
+    t.filter = filter_pass; t.n_filter = n_filter;
+    std::vector<float> zeros;
+    const float *dres = nullptr;
+    while (t.advance(dres, nullptr)) { zeros.assign(t.dist_ids.size(), 0.0f); dres = zeros.data(); }
+    const uint32_t c = (uint32_t)t.out_tid.size();
+    for (uint32_t k = 0; k < c; k++) { tids_out[k] = t.out_tid[k]; if (elems_out) elems_out[k] = t.out_elem[k]; }
+    *count_out = c;
+    return HX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // f1: graph -> PostgreSQL HNSW index pages.  One forward pass over the elements: a cursor (current block, its
 // pd_lower / pd_upper) places the element tuple and then the neighbour tuple exactly where PageAddItemExtended would

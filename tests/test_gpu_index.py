@@ -222,6 +222,40 @@ def test_regress_orderings_on_device(case):
     e.close()
 
 
+@pytest.mark.parametrize("case", G["null_query_count"], ids=lambda c: c["ref"].split("/")[-1])
+def test_null_and_zero_query_counts_on_device(case):
+    """`ORDER BY val <-> (SELECT NULL::vector)` and the zero-vector cosine query of the reference's pg_regress files (scan.rs:186-187) on an index the
+    device built: the expected counts, and -- with a NULL query every distance is 0.0, so the order is pure BinaryHeap tie behaviour -- the oracle's order."""
+    dt = TYPE[case["type"]]
+    cosine = case["metric"] == "cosine"
+    enc_rows = [enc(case["type"], r) for r in case["rows"]]
+    dim = enc_rows[0][1]
+    e = hx.Engine(dt, METRIC[case["metric"]], dim, 16)
+    ix = hx.Index(e, 16, 64)
+    o = orc.Index(dt, METRIC[case["metric"]], dim, m=16, ef_construction=64, order=orc.W64)
+    for tid, (r, _) in enumerate(enc_rows):
+        first = e.append(r[None, :] if r.ndim == 1 else r)
+        if cosine:
+            if e.normalize_rows(first, 1)[0] == 0.0:
+                e.pop(1)
+                continue
+        ix.insert(first, [0], tids=[tid], batch=1)
+        o.insert(e.read_rows(first, 1)[0], 0, tid)
+    if "query" in case:
+        q, _ = enc(case["type"], case["query"])
+        e.set_queries(q[None, :], normalize=cosine)
+        tids, _, _, cnt = ix.search(1, 40, 10)
+        got = tids[0, :cnt[0]].tolist()
+        want = [t for t, _, _ in o.scan(orc.l2_normalize(dt, dim, q)[0] if cosine else q)]
+    else:
+        got = ix.search_null(40, 10)[0].tolist()
+        want = [t for t, _, _ in o.scan(None)]
+    assert len(got) == case["expect_count"]
+    assert got == want
+    ix.close()
+    e.close()
+
+
 def test_duplicates_20_identical_rows_on_device():
     """tests/t/015_hnsw_vector_duplicates.pl:24-37 through the device path."""
     e = hx.Engine(hx.F32, hx.L2SQ, 3, 32)
