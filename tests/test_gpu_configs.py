@@ -20,7 +20,7 @@ from test_gpu_index import assert_same_graph, build_both
 pytestmark = pytest.mark.gpu
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
 METRIC = {"l2": hx.L2SQ, "ip": hx.NEG_IP, "cosine": hx.NEG_IP, "l1": hx.L1, "hamming": hx.HAMMING, "jaccard": hx.JACCARD}
-TYPE = {"vector": hx.F32, "halfvec": hx.F16, "bit": hx.BIT}
+TYPE = {"vector": hx.F32, "halfvec": hx.F16, "bit": hx.BIT, "sparsevec": hx.SPARSE}
 
 
 def _seq_tolerance_report(name, dt, metric, dim, e, rows, qs, record_property):
@@ -141,6 +141,9 @@ def _gate_rows(gate, rng):
     qraw = rng.random((gate["queries"], dim)).astype(np.float32)
     if gate["type"] == "halfvec":
         return raw.astype(np.float16).view(np.uint16), qraw.astype(np.float16).view(np.uint16), raw.astype(np.float16).astype(np.float64), qraw.astype(np.float16).astype(np.float64)
+    if gate["type"] == "sparsevec":                                                                    # ARRAY[...]::vector::sparsevec, 028:11,57: the non-zero elements
+        pack = lambda a: hx.pack_sparse(dim, [(np.nonzero(r)[0], r[np.nonzero(r)[0]]) for r in a])
+        return pack(raw), pack(qraw), raw.astype(np.float64), qraw.astype(np.float64)
     return raw, qraw, raw.astype(np.float64), qraw.astype(np.float64)
 
 
@@ -163,7 +166,8 @@ def _exact(gate, metric, rows, q, r64, q64):
 
 @pytest.mark.parametrize("gate", G["recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
 def test_reference_recall_gates_on_device(gate):
-    """tests/t/012:94, 024:97, 020:102 at their full size (10 000 rows, k = 20) through the batched device build and device scan."""
+    """tests/t/012:94, 024:97, 020:102, 028:102 at their full size (10 000 rows, k = 20) through the batched device build and device scan
+    (sparsevec: the lock-step driver on the merge-join kernels)."""
     rng = np.random.default_rng(12)
     n, dim, k = gate["rows"], gate["dim"], gate["k"]
     dt = TYPE[gate["type"]]

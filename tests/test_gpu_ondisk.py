@@ -9,6 +9,7 @@ import pytest
 
 import pgvector_rx_amd as hx
 from oracle import orc
+from test_gpu_configs import TYPE as GTYPE, METRIC as GMETRIC, _exact, _gate_rows
 from test_gpu_index import assert_same_graph, build_both, make_rows
 
 pytestmark = pytest.mark.gpu
@@ -106,18 +107,17 @@ def test_vacuum_identical_to_oracle(dtype, metric, dim, m, efc):
 
 @pytest.mark.parametrize("gate", G["insert_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
 def test_insert_recall_gate_on_device(gate):
-    """tests/t/013_hnsw_vector_insert_recall.pl:104 at its full size: 10 000 rows inserted through aminsert, 10 at a time (the test's 10
-    concurrent pgbench clients), recall@20 >= 0.99 (0.97 inner product)."""
+    """tests/t/013:104, 021:109, 025:106, 029:103 at their full size: 10 000 rows inserted through aminsert, 10 at a time (the tests' 10 concurrent
+    pgbench clients), recall@20 above the reference's thresholds for every operator class of the type (ties with the k-th distance count, as in 021:60-66)."""
     rng = np.random.default_rng(13)
     n, dim, k = gate["rows"], gate["dim"], gate["k"]
-    raw = (rng.random((n, dim)) * rng.random((n, dim))).astype(np.float32)
-    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    dt = GTYPE[gate["type"]]
+    rows, qs, r64, q64 = _gate_rows(gate, rng)
     levels = hx.draw_levels(n, gate["m"], seed=13)
-    r64, q64 = raw.astype(np.float64), qs.astype(np.float64)
     for metric, min_recall in gate["min_recall"].items():
         cosine = metric == "cosine"
-        e = hx.Engine(hx.F32, METRIC[metric], dim, n)
-        e.append(raw)
+        e = hx.Engine(dt, GMETRIC[metric], dim, n)
+        e.append(rows)
         if cosine:
             assert (e.normalize_rows(0, n) > 0).all()
         ix = hx.Index(e, gate["m"], gate["ef_construction"])
@@ -126,16 +126,11 @@ def test_insert_recall_gate_on_device(gate):
         tids, _, _, cnt = ix.search(len(qs), gate["ef_search"], k)
         correct = 0
         for q in range(len(qs)):
-            if metric == "l2":
-                dist = ((r64 - q64[q]) ** 2).sum(1)
-            elif metric == "ip":
-                dist = -(r64 @ q64[q])
-            elif metric == "l1":
-                dist = np.abs(r64 - q64[q]).sum(1)
-            else:
-                dist = 1.0 - (r64 @ q64[q]) / np.sqrt((r64 ** 2).sum(1) * (q64[q] ** 2).sum())
-            correct += len(set(np.argsort(dist, kind="stable")[:k].tolist()) & set(tids[q, :cnt[q]].tolist()))
-        assert correct / (k * len(qs)) >= min_recall, (metric, correct / (k * len(qs)))
+            dist = _exact(gate, metric, rows, qs[q], r64, None if q64 is None else q64[q])
+            kth = np.sort(dist, kind="stable")[k - 1]
+            ok = set(np.nonzero(dist <= kth)[0].tolist())
+            correct += sum(1 for t in tids[q, :cnt[q]].tolist() if t in ok)
+        assert correct / (k * len(qs)) >= min_recall, (gate["ref"], metric, correct / (k * len(qs)))
         ix.close()
         e.close()
 

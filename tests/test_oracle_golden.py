@@ -231,10 +231,11 @@ def test_duplicates_20_identical_rows():
 
 
 # ---- statistical recall gates (tests/t/012, 020, 024) -------------------------------------------
-def _exact_topk(tname, metric, rows, q, k):
+def _exact_topk(tname, metric, rows, q, k, dim=None):
     L = orc.lib()
     dt = TYPE[tname]
-    dim = rows.shape[1] if tname != "bit" else None
+    if dim is None:
+        dim = rows.shape[1] if tname != "bit" else None
     d = []
     for r in rows:
         if metric == "cosine":
@@ -263,6 +264,9 @@ def test_recall_gates(gate):
         if tname == "halfvec":
             rows = raw.astype(np.float16).view(np.uint16)
             qs = qraw.astype(np.float16).view(np.uint16)
+        elif tname == "sparsevec":                # ARRAY[random() * random(), ...]::vector::sparsevec, 028:11,57
+            rows = np.stack([orc.sparse_from_dense(r) for r in raw])
+            qs = np.stack([orc.sparse_from_dense(r) for r in qraw])
         else:
             rows, qs = raw, qraw
     levels = orc.levels_from_seed(n, gate["m"], 7)
@@ -278,7 +282,7 @@ def test_recall_gates(gate):
             idx.insert(r, levels[i], i)
         correct = total = 0
         for q in qs:
-            dists, exact = _exact_topk(tname, metric, rows, q, k)
+            dists, exact = _exact_topk(tname, metric, rows, q, k, dim if tname == "sparsevec" else None)
             qq = q
             if metric == "cosine":
                 qq, _ = orc.l2_normalize(dt, dim, q)
@@ -384,29 +388,49 @@ def _live_recall(idx, qs, exact, ef_search, k, alive):
     return correct / (k * len(qs))
 
 
+def _gate_data(gate, rng, n):
+    """Rows and queries with the distributions of the reference's recall tests (012:11, 020:62, 024:12, 028:11), encoded for the oracle."""
+    tname, dim = gate["type"], gate["dim"]
+    if tname == "bit":
+        rows = np.packbits(rng.integers(0, 2, (n, dim)).astype(np.uint8), axis=1, bitorder="big")
+        qs = np.packbits(rng.integers(0, 2, (gate["queries"], dim)).astype(np.uint8), axis=1, bitorder="big")
+        return rows, qs
+    scale = 2.0 if tname == "halfvec" else 1.0
+    raw = (scale * rng.random((n, dim)) * rng.random((n, dim))).astype(np.float32)
+    qraw = rng.random((gate["queries"], dim)).astype(np.float32)
+    if tname == "halfvec":
+        return raw.astype(np.float16).view(np.uint16), qraw.astype(np.float16).view(np.uint16)
+    if tname == "sparsevec":
+        return np.stack([orc.sparse_from_dense(r) for r in raw]), np.stack([orc.sparse_from_dense(r) for r in qraw])
+    return raw, qraw
+
+
 @pytest.mark.parametrize("gate", G["insert_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
 def test_insert_recall_gate(gate):
-    """tests/t/013: an index filled ONLY through aminsert (find_element_neighbors_on_disk + get_update_index) reaches the build path's recall."""
+    """tests/t/013, 021, 025, 029: an index filled ONLY through aminsert (find_element_neighbors_on_disk + get_update_index) reaches the build path's
+    recall, for every operator class of vector, bit, halfvec and sparsevec."""
     rng = np.random.default_rng(13)
-    n, dim, k = 3000, gate["dim"], gate["k"]                  # the gate is size-free; 3000 rows keep the CPU suite short
-    raw = (rng.random((n, dim)) * rng.random((n, dim))).astype(np.float32)
-    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    n, dim, k = 2000, gate["dim"], gate["k"]                  # the gate is size-free; 2000 rows keep the CPU suite short
+    tname = gate["type"]
+    dt = TYPE[tname]
+    rows, qs = _gate_data(gate, rng, n)
     levels = orc.levels_from_seed(n, gate["m"], 13)
     for metric, min_recall in gate["min_recall"].items():
-        idx = orc.Index(orc.F32, METRIC[metric], dim, m=gate["m"], ef_construction=gate["ef_construction"])
+        idx = orc.Index(dt, METRIC[metric], dim, m=gate["m"], ef_construction=gate["ef_construction"])
         for i in range(n):
-            r = raw[i]
+            r = rows[i]
             if metric == "cosine":
-                r, norm = orc.l2_normalize(orc.F32, dim, r)
+                r, norm = orc.l2_normalize(dt, dim, r)
                 if norm == 0.0:
                     continue
             idx.insert_on_disk(r, levels[i], i)
         correct = 0
         for q in qs:
-            _, exact = _exact_topk("vector", metric, raw, q, k)
-            qq = orc.l2_normalize(orc.F32, dim, q)[0] if metric == "cosine" else q
+            dists, exact = _exact_topk(tname, metric, rows, q, k, dim if tname == "sparsevec" else None)
+            qq = orc.l2_normalize(dt, dim, q)[0] if metric == "cosine" else q
             got = [t for t, _, _ in idx.scan(qq, ef_search=gate["ef_search"], limit=k)]
-            correct += len(set(exact.tolist()) & set(got))
+            ok = set(np.nonzero(dists <= dists[exact[-1]])[0].tolist())          # ties with the k-th distance count (021:60-66)
+            correct += sum(1 for t in got if t in ok)
         assert correct / (k * len(qs)) >= min_recall, (metric, correct / (k * len(qs)))
 
 
