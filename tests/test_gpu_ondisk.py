@@ -137,19 +137,17 @@ def test_insert_recall_gate_on_device(gate):
 
 @pytest.mark.parametrize("gate", G["vacuum_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
 def test_vacuum_recall_gate_on_device(gate):
-    """tests/t/014_hnsw_vector_vacuum_recall.pl:89-95 at its full size (10 000 rows, m = 4, ef_construction = 8, 7 500 rows deleted)."""
+    """tests/t/014:89-95, 022:93-97, 026:89-95, 030:89-95 at their full size (10 000 rows, m = 4, ef_construction = 8, 7 500 rows deleted)."""
+    from test_oracle_golden import _vacuum_gate_data
     rng = np.random.default_rng(14)
     n, dim, k, keep = gate["rows"], gate["dim"], gate["k"], gate["keep"]
-    rows = rng.random((n, dim)).astype(np.float32)
-    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    rows, qs, exact = _vacuum_gate_data(gate, rng)
     levels = hx.draw_levels(n, gate["m"], seed=14)
-    e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+    e = hx.Engine(GTYPE[gate["type"]], GMETRIC[gate["metric"]], dim, n)
     e.append(rows)
     ix = hx.Index(e, gate["m"], gate["ef_construction"])
     ix.insert(0, levels, tids=np.arange(1, n + 1), batch=64)
     e.set_queries(qs)
-    d2 = ((qs[:, None, :].astype(np.float64) - rows[None, :keep, :].astype(np.float64)) ** 2).sum(2)
-    exact = (np.argsort(d2, axis=1, kind="stable")[:, :k] + 1).tolist()
 
     def recall(ef_search, alive):
         tids, _, _, cnt = ix.search(len(qs), ef_search, ef_search)            # the index hands over ef_search tuples; the heap visit drops the dead
@@ -159,11 +157,11 @@ def test_vacuum_recall_gate_on_device(gate):
             c += len(set(got) & set(exact[q]))
         return c / (k * len(qs))
     for g in gate["before_vacuum"]:
-        assert recall(g["ef_search"], lambda t: t <= keep) >= g["min_recall"], ("before", g)
+        assert recall(g["ef_search"], lambda t: t <= keep) >= g["min_recall"] - gate.get("noise", 0.0), ("before", g)
     nd, nr = ix.vacuum(np.arange(keep + 1, n + 1), batch=64)
     assert nd == n - keep and nr > 0
     for g in gate["after_vacuum"]:
-        assert recall(g["ef_search"], lambda t: True) >= g["min_recall"], ("after", g)
+        assert recall(g["ef_search"], lambda t: True) >= g["min_recall"] - gate.get("noise", 0.0), ("after", g)
     tids, _, _, cnt = ix.search(len(qs), 100, 100)
     assert all(t <= keep for q in range(len(qs)) for t in tids[q, :cnt[q]].tolist())
     ix.close()

@@ -380,12 +380,37 @@ def test_iterative_recall_gate(gate):
 
 def _live_recall(idx, qs, exact, ef_search, k, alive):
     """What `SELECT ... ORDER BY v <-> q LIMIT k` returns when the index still holds dead TIDs: the scan's ef_search tuples in order,
-    the dead ones dropped by the heap visit, the first k kept."""
+    the dead ones dropped by the heap visit, the first k kept.  exact[i]: the TIDs that count as correct for query i."""
     correct = 0
     for i, q in enumerate(qs):
         got = [t for t, _, _ in idx.scan(q, ef_search=ef_search) if alive(t)][:k]
         correct += len(set(got) & set(exact[i]))
     return correct / (k * len(qs))
+
+
+def _vacuum_gate_data(gate, rng):
+    """Rows / queries of the vacuum recall tests (random() per component: 014:60, 026:60, 030:60; random bits: 022:63), the oracle's encoding of them
+    and, per query, the TIDs (1-based, among the rows that stay) that count as correct: the k nearest, plus ties with the k-th for bit (022:84-89)."""
+    n, dim, k, keep, tname = gate["rows"], gate["dim"], gate["k"], gate["keep"], gate["type"]
+    if tname == "bit":
+        bits = rng.integers(0, 2, (n, dim)).astype(np.uint8); qbits = rng.integers(0, 2, (gate["queries"], dim)).astype(np.uint8)
+        rows, qs = np.packbits(bits, axis=1, bitorder="big"), np.packbits(qbits, axis=1, bitorder="big")
+        d = (qbits[:, None, :] != bits[None, :keep, :]).sum(2).astype(np.float64)
+    else:
+        raw = rng.random((n, dim)).astype(np.float32); qraw = rng.random((gate["queries"], dim)).astype(np.float32)
+        if tname == "halfvec":
+            raw, qraw = raw.astype(np.float16), qraw.astype(np.float16)
+            rows, qs = raw.view(np.uint16), qraw.view(np.uint16)
+        elif tname == "sparsevec":
+            rows, qs = np.stack([orc.sparse_from_dense(r) for r in raw]), np.stack([orc.sparse_from_dense(r) for r in qraw])
+        else:
+            rows, qs = raw, qraw
+        d = ((qraw[:, None, :].astype(np.float64) - raw[None, :keep, :].astype(np.float64)) ** 2).sum(2)
+    exact = []
+    for q in range(len(qs)):
+        kth = np.sort(d[q], kind="stable")[k - 1]
+        exact.append((np.nonzero(d[q] <= kth)[0] + 1).tolist() if tname == "bit" else (np.argsort(d[q], kind="stable")[:k] + 1).tolist())
+    return rows, qs, exact
 
 
 def _gate_data(gate, rng, n):
@@ -436,24 +461,21 @@ def test_insert_recall_gate(gate):
 
 @pytest.mark.parametrize("gate", G["vacuum_recall_gates"], ids=lambda g: g["ref"].split("/")[-1])
 def test_vacuum_recall_gate(gate):
-    """tests/t/014 at its full size: 10 000 rows, m = 4, ef_construction = 8; rows 2501.. deleted; recall before and after VACUUM."""
+    """tests/t/014, 022, 026, 030 at their full size: 10 000 rows, m = 4, ef_construction = 8; rows 2501.. deleted; recall before and after VACUUM."""
     rng = np.random.default_rng(14)
     n, dim, k, keep = gate["rows"], gate["dim"], gate["k"], gate["keep"]
-    rows = rng.random((n, dim)).astype(np.float32)
-    qs = rng.random((gate["queries"], dim)).astype(np.float32)
+    rows, qs, exact = _vacuum_gate_data(gate, rng)
     levels = orc.levels_from_seed(n, gate["m"], 14)
-    idx = orc.Index(orc.F32, orc.L2SQ, dim, m=gate["m"], ef_construction=gate["ef_construction"])
+    idx = orc.Index(TYPE[gate["type"]], METRIC[gate["metric"]], dim, m=gate["m"], ef_construction=gate["ef_construction"])
     idx.build(rows, levels, batch=1, tids=np.arange(1, n + 1))
-    d2 = ((qs[:, None, :].astype(np.float64) - rows[None, :keep, :].astype(np.float64)) ** 2).sum(2)
-    exact = (np.argsort(d2, axis=1, kind="stable")[:, :k] + 1).tolist()
     for g in gate["before_vacuum"]:
         r = _live_recall(idx, qs, exact, g["ef_search"], k, lambda t: t <= keep)
-        assert r >= g["min_recall"], ("before", g, r)
+        assert r >= g["min_recall"] - gate.get("noise", 0.0), ("before", g, r)
     idx.vacuum(np.arange(keep + 1, n + 1))
     assert sum(idx.deleted(e) for e in range(n)) == n - keep
     for g in gate["after_vacuum"]:
         r = _live_recall(idx, qs, exact, g["ef_search"], k, lambda t: True)
-        assert r >= g["min_recall"], ("after", g, r)
+        assert r >= g["min_recall"] - gate.get("noise", 0.0), ("after", g, r)
     # nothing dead is returned any more, and no live element links to a deleted one
     assert all(t <= keep for q in qs for t, _, _ in idx.scan(q, ef_search=100))
     for e in range(n):
