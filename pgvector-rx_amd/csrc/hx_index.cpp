@@ -805,6 +805,9 @@ struct hx_index {
     int fail(int code, const std::string &m) { err = m; return code; }
 
     bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192 && e->dtype != HX_SPARSE; }   // sparsevec: lock-step driver (merge-join kernels)
+    // scans: the traversal kernel walks lists longer than a wavefront 64 ids at a time, so every m the reference allows (options.rs:203-225: m <= 100) is served;
+    // only the insert-mode kernel and the back-link kernels are built for lists of <= 64
+    bool fused_scan_ok() const { return fused && e->pitch <= 8192 && e->dtype != HX_SPARSE; }
     // device-resident batches (hx_batch.hip): the traversal kernel and the back-link kernels both serve this m
     bool dbatch_ok() const { static const bool off = getenv("HX_DEVICE_BATCH") && atoi(getenv("HX_DEVICE_BATCH")) == 0; return !off && fused_ok() && 2 * g.m <= 64; }
     void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
@@ -2042,7 +2045,7 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
     if (ef_search < 1 || ef_search > 1000) return ix->fail(HX_E_ARG, "hnsw.ef_search must be between 1 and 1000");   // options.rs:156-166
     if (nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
     std::vector<uint32_t> todo;                                  // query slots for the lock-step path
-    if (mode == 0 && ix->fused_ok() && ix->g.entry >= 0) {
+    if (mode == 0 && ix->fused_scan_ok() && ix->g.entry >= 0) {
         const double t_sm0 = hx_index::now_s();
         int rc = ix->sync_mirror();
         if (rc) return rc;
@@ -2108,7 +2111,7 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
         }
         ix->fused_tasks += nq; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
-    } else if (mode != 0 && ix->fused_ok() && ix->g.entry >= 0 && limit <= 4096) {
+    } else if (mode != 0 && ix->fused_scan_ok() && ix->g.entry >= 0 && limit <= 4096) {
         // iterative scan on the device (k_fused MODE 2): the filter reaches the kernel as a per-element mask of passing heap TIDs
         int rc = ix->sync_mirror();
         if (rc) return rc;

@@ -734,6 +734,33 @@ def test_overflowed_tasks_are_retried_on_the_device_with_roomier_tables():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,metric,dim,m", [(hx.F32, hx.L2SQ, 6, 40), (hx.BIT, hx.HAMMING, 64, 100)])
+def test_scans_run_in_the_traversal_kernel_for_every_legal_m(dtype, metric, dim, m):
+    """m in 33..100 (options.rs:203-225): the build falls to the lock-step driver (the insert and back-link kernels serve lists of <= 64), but plain and
+    iterative scans still run inside k_fused, which walks a layer-0 list of up to 200 ids 64 at a time -- same tids as the oracle."""
+    rng = np.random.default_rng(m)
+    n, efc = 1200, 2 * m
+    rows = make_rows(dtype, n, dim, rng)
+    levels = hx.draw_levels(n, m, seed=m)
+    e, ix, _, o, _ = build_both(dtype, metric, dim, rows, levels, m, efc, 64)
+    assert_same_graph(ix, o, n)
+    qs = make_rows(dtype, 16, dim, rng)
+    e.set_queries(qs)
+    before = ix.fused_stats()
+    tids, d, el, cnt = ix.search(16, 60, 10)
+    passes = (np.arange(n) % 7 == 0).astype(np.uint8)
+    it = ix.search_iterative(16, 60, 1, 20000, 8, passes)
+    after = ix.fused_stats()
+    assert after["tasks"] == before["tasks"] + 32 and after["redone"] == before["redone"]
+    for q in range(16):
+        assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=60, limit=10)]
+        want = [t for t, _, _ in o.scan(qs[q], ef_search=60, iterative=orc.ITER_RELAXED, max_scan_tuples=20000) if passes[t]][:8]
+        assert it[0][q, :it[2][q]].tolist() == want
+    ix.close()
+    e.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ties", [False, True])
 @pytest.mark.parametrize("dtype,metric,dim", [(hx.F32, hx.L2SQ, 24), (hx.F16, hx.NEG_IP, 40), (hx.F32, hx.L1, 300)])
 def test_sorted_array_search_equals_the_heap_search(dtype, metric, dim, ties):
