@@ -141,6 +141,9 @@ def run(name, n, data="baseline"):
     if iterative:
         passes = (np.arange(n) % iterative["filter_every"] == 0).astype(np.uint8)
         nqi = int(os.environ.get("HX_ITER_QUERIES", "500"))
+        t0 = time.perf_counter()
+        ix.search_iterative(nqi, efs, iterative["mode"], iterative["max_scan_tuples"], iterative["limit"], passes)   # first call: allocates the per-query tables (GBs)
+        it_first_s = time.perf_counter() - t0
         ix.profile(reset=True)
         t0 = time.perf_counter()
         it_tids, it_d, it_cnt = ix.search_iterative(nqi, efs, iterative["mode"], iterative["max_scan_tuples"], iterative["limit"], passes)
@@ -169,6 +172,7 @@ def run(name, n, data="baseline"):
         cpu_it = len(hq) / (time.perf_counter() - t0)
         del o
         out["iterative_relaxed_cpu_oracle_1core_qps"] = round(cpu_it, 1)
+        out["iterative_relaxed_first_call_qps"] = round(nqi / it_first_s, 1)
         out["iterative_relaxed"] = {"queries": nqi, "filter": "tid %% %d == 0" % iterative["filter_every"], "max_scan_tuples": iterative["max_scan_tuples"],
                                     "qps": round(nqi / it_s, 1), "recall_at_10": round(recall(it_tids, it_cnt, gti, k), 4),
                                     "mean_returned": float(it_cnt.mean()), "path": "k_fused MODE 2 (device-resident iterative scan); lock-step host driver when set_fused(False)", "host_profile": it_prof}
