@@ -19,13 +19,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_batched_device_build_recall_equals_sequential_reference_schedule(record_property):
-    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "recall_parity_100k.json")))
+FIXTURES = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.startswith("recall_parity_") and f.endswith(".json"))
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_batched_device_build_recall_equals_sequential_reference_schedule(fixture, record_property):
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", fixture)))
     spec = importlib.util.spec_from_file_location("make_recall_fixture", os.path.join(ROOT, "tools", "make_recall_fixture.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)                                       # the committed generator: same numpy streams as the fixture run
     rows, qs = gen.make_data(fx)
     n, dim, k = fx["rows"], fx["dim"], fx["k"]
+    assert len(rows) == n
     levels = hx.draw_levels(n, fx["m"], seed=fx["seed_levels"])
     e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
     e.append(rows)

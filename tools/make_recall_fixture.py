@@ -4,7 +4,7 @@ build_callback, ORC_ORDER_SEQ, one row at a time) on 100 000 x vector(768) L2, m
 shape and data distribution at a size one CPU core finishes in under an hour.  tests/test_gpu_recall_parity.py rebuilds the same rows
 with the batched device build (batch cap 8192) and demands the same recall within sampling noise.
 
-Run once on a CPU box:  python tools/make_recall_fixture.py      (takes ~30-40 min; commit the JSON it writes)"""
+Run once on a CPU box:  python tools/make_recall_fixture.py [rows]     (100 000 rows: 10 min of one core, 300 000: ~40 min; commit the JSON it writes)"""
 import json
 import os
 import sys
@@ -45,7 +45,9 @@ def exact_topk(rows, qs, k):
 
 
 def main():
-    cfg = CFG
+    cfg = dict(CFG)
+    if len(sys.argv) > 1:                                      # python tools/make_recall_fixture.py 300000 -> tests/golden/recall_parity_300k.json
+        cfg["rows"] = int(sys.argv[1])
     rows, qs = make_data(cfg)
     levels = hx.draw_levels(cfg["rows"], cfg["m"], seed=cfg["seed_levels"])
     o = orc.Index(orc.F32, orc.L2SQ, cfg["dim"], m=cfg["m"], ef_construction=cfg["ef_construction"], order=orc.SEQ)
@@ -67,7 +69,7 @@ def main():
                                         "hits_per_query": "".join("%x" % int(round(v * cfg["k"])) for v in per_q)}   # one hex digit per query (k = 10): lets the device test compare query by query
         print("ef_search %d: recall@%d %.4f" % (efs, cfg["k"], per_q.mean()), flush=True)
     out["distance_evaluations"] = {"search": o.counters()[1], "select": o.counters()[2], "backlink": o.counters()[3]}
-    path = os.path.join(ROOT, "tests", "golden", "recall_parity_100k.json")
+    path = os.path.join(ROOT, "tests", "golden", "recall_parity_%dk.json" % (cfg["rows"] // 1000))
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
 
