@@ -318,7 +318,8 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     }
     if (mode == 2) memcpy(it->out_tix, mr.h_io + o_tix, out_n * 4);
     unsigned long long nd[17]; memcpy(nd, mr.h_io + o_ctr + 8, 136);
-    if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))
+    if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4) && !FUSED_TIMERS_ON) { static bool once = false; if (!once) { once = true; fprintf(stderr, "[hx] HX_F_DBG=4: this library was built without -DFUSED_TIMERS (HX_CFLAGS=-DFUSED_TIMERS python pgvector-rx_amd/build.py --force)\n"); } }
+    if (FUSED_TIMERS_ON && getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))
         fprintf(stderr, "[hx] k_fused mode %d tasks %u: shader-clock ticks (s_memtime) summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu; select phase %llu\n",
                 mode, ntasks, nd[3], nd[4], nd[5], nd[6], nd[7], nd[8], nd[9], nd[10], nd[11], nd[12], nd[13], nd[14], nd[15], nd[16]);
     if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }

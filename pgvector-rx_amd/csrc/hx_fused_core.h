@@ -12,6 +12,13 @@
 #ifndef FUSED_MINW
 #define FUSED_MINW 4
 #endif
+// In-kernel phase clocks (HX_F_DBG=4): compiled in only with -DFUSED_TIMERS (HX_CFLAGS=-DFUSED_TIMERS python pgvector-rx_amd/build.py --force) -- a dozen
+// `if (timers)` branches per expansion and fourteen live counters cost the shipped kernels registers and issue slots for a diagnostic.
+#ifdef FUSED_TIMERS
+#define FUSED_TIMERS_ON true
+#else
+#define FUSED_TIMERS_ON false
+#endif
 #define FUSED_SLOTS_PER_CU 24u     /* the per-wave spill areas and visited tables are sized for this many resident searches per CU */
 #ifndef FUSED_MINW_SA
 #define FUSED_MINW_SA 4             /* the sorted-array query kernel */

@@ -141,7 +141,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     for (;;) {
         if (cx.status != FS_OK) break;
         // pop the nearest candidate, decide whether to stop
-        const bool tm = (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+        const bool tm = FUSED_TIMERS_ON && (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
         // The candidate about to be popped is the heap's root: read it, decide, and put its neighbour list's loads in
         // flight BEFORE the pop's heap maintenance, which then hides that memory hop.
         uint32_t go = 0, cid = 0;
@@ -305,7 +305,7 @@ __device__ void f_search_layer_sa(const FusedParams &p, FusedCtx &cx, uint32_t n
     uint32_t len = n_ep;
     F_BAR();
     while (cx.status == FS_OK) {
-        const bool tm = (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+        const bool tm = FUSED_TIMERS_ON && (p.fdbg & 4u) != 0; unsigned long long t0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
         // the nearest unexpanded member of W (mod.rs:187-193)
         uint32_t pos = 0xffffffffu;
 #pragma unroll
@@ -607,7 +607,7 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
                     F_BAR();
                 }
                 // select_neighbors(W, lm): mod.rs:269-308
-                const unsigned long long ts0 = (p.fdbg & 4u) ? __builtin_amdgcn_s_memtime() : 0ull;
+                const unsigned long long ts0 = (FUSED_TIMERS_ON && (p.fdbg & 4u)) ? __builtin_amdgcn_s_memtime() : 0ull;
                 uint32_t r = 0, nd = 0;
                 if (wl <= lm) {
                     for (uint32_t i = lane; i < wl; i += 64) cx.RL[i] = cx.EP[i];
@@ -662,14 +662,14 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
                 for (uint32_t i = lane; i < r; i += 64) { const uint2 v = cx.RL[i]; p.out_ids[lb + i] = v.y; p.out_d[lb + i] = fh_d(v); }
                 if (lane == 0) p.out_cnt[obase + lc] = r;
                 F_BAR();
-                if (p.fdbg & 4u) cx.tph[13] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts0);
+                if (FUSED_TIMERS_ON && (p.fdbg & 4u)) cx.tph[13] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts0);
             }
             if (lane == 0) p.status[t] = cx.status;
         }
         F_BAR();
     }
     if (lane == 0) { atomicAdd(&p.n_dist[0], cx.nd0); atomicAdd(&p.n_dist[1], cx.nd1); atomicMax(&p.n_dist[2], (unsigned long long)cx.cmax);
-                     if (p.fdbg & 4u) { for (int i = 0; i < 14; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
+                     if (FUSED_TIMERS_ON && (p.fdbg & 4u)) { for (int i = 0; i < 14; i++) atomicAdd(&p.n_dist[3 + i], (unsigned long long)cx.tph[i]); } }
 }
 
 template <class OP, int MODE, int LPR, bool SA = false>
