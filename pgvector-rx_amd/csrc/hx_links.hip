@@ -445,7 +445,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     unsigned long long ndist = 0;
 
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
-    const bool tm = (p.dbg & 8u) != 0; const unsigned long long tk0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;
+    const bool tm = FUSED_TIMERS_ON && (p.dbg & 8u) != 0; const unsigned long long tk0 = tm ? __builtin_amdgcn_s_memtime() : 0ull;   // phase clocks: -DFUSED_TIMERS builds only
     for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++)
         (void)lc_op<OP, LPR, false, SLOTS>(fp, p, M, M2, lid, ld, lid2, ld2, nd, pos, sd, sel, dis, ORD, IDS, QV, cnt, v, lm, p.op_new[op], p.op_d[op], lane, ndist, tm ? tk : nullptr,
                                     lk_wtab(p, layer, p.op_new[op]), p.wt_size - 1u);
@@ -751,7 +751,7 @@ int hx_engine::links_run(uint32_t n_groups, const uint32_t *target, const uint32
     HX_HIP(this, hipStreamSynchronize(stream));
     *out_cnt = (const uint32_t *)(h + o_cnt); *out_ids = (const uint32_t *)(h + o_ids); *out_d = (const float *)(h + o_d);
     unsigned long long np; memcpy(&np, h + o_ctr, 8);
-    if (p.dbg & 8u) { unsigned long long t[7]; memcpy(t, h + o_ctr, 56); fprintf(stderr, "[hx] k_links_cached groups %u ops %u: ticks matrix-fill %llu sort %llu walk %llu lazy-nd %llu rebuild %llu; whole kernel per wave %llu\n", n_groups, n_ops, t[1], t[2], t[3], t[4], t[5], t[6]); }
+    if (FUSED_TIMERS_ON && (p.dbg & 8u)) { unsigned long long t[7]; memcpy(t, h + o_ctr, 56); fprintf(stderr, "[hx] k_links_cached groups %u ops %u: ticks matrix-fill %llu sort %llu walk %llu lazy-nd %llu rebuild %llu; whole kernel per wave %llu\n", n_groups, n_ops, t[1], t[2], t[3], t[4], t[5], t[6]); }
     if (n_pairs) *n_pairs = np;
     if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
     return HX_OK;
