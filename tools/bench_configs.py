@@ -138,6 +138,37 @@ def run(name, n, data="baseline"):
            "k_fused_insert_GBps": round(bstats["fused_insert"]["units"] * row_bytes / max(bstats["fused_insert"]["ms"], 1e-9) / 1e6, 1),
            "k_fused_insert_ms": round(bstats["fused_insert"]["ms"], 1), "k_links_ms": round(bstats["links"]["ms"], 1),
            "fused": ix.fused_stats(), "host_profile": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ix.profile().items()}}
+    if name == "c4":
+        # configs[3]: "fp16 MFMA batched-build distance GEMM".  The operands of select_neighbors are blocks of <= 64 rows that lie close together in the
+        # graph: an element, its layer-0 neighbours and theirs.  k_pair_mfma_f16 (matrix cores) against k_pair_groups (exact VALU order) on such blocks
+        # of THIS index; utilisation against the 2.5 PFLOP/s dense f16 peak (MI355X_MICROARCH.md).
+        rng = np.random.default_rng(4)
+        groups = []
+        for x in rng.integers(0, n, 8192).tolist():
+            ids = [x]
+            seen = {x}
+            nb = ix.neighbors(x, 0)[0].tolist()
+            for y in nb + [z for y in nb[:4] for z in ix.neighbors(int(y), 0)[0].tolist()]:
+                if y not in seen and len(ids) < 64:
+                    seen.add(y); ids.append(int(y))
+            if len(ids) >= 33:
+                groups.append((ids, None))
+        pairs = sum(len(g[0]) * (len(g[0]) - 1) // 2 for g in groups)
+        tiles = sum(3 if len(g[0]) > 32 else 1 for g in groups)
+        mf = {}
+        for kind, on in ((4, True), (1, False)):
+            eng.pairwise_many(groups, mfma=on)
+            eng.kernel_stats(kind, reset=True)
+            for _ in range(3):
+                eng.pairwise_many(groups, mfma=on)
+            st = eng.kernel_stats(kind, reset=True)
+            mf["mfma" if on else "valu"] = st["ms"] / st["launches"]
+        flops_issued = tiles * 2.0 * 32 * 32 * (64 * ((dim + 63) // 64))
+        out["select_operand_blocks"] = {"blocks": len(groups), "rows_per_block": "33-64 (an element, its layer-0 neighbours and theirs)", "pairs": pairs,
+                                        "k_pair_mfma_f16_ms": round(mf["mfma"], 3), "k_pair_groups_ms": round(mf["valu"], 3),
+                                        "mfma_Gpairs_per_s": round(pairs / mf["mfma"] / 1e6, 2), "valu_Gpairs_per_s": round(pairs / mf["valu"] / 1e6, 2),
+                                        "mfma_TFLOPs_issued": round(flops_issued / mf["mfma"] / 1e9, 1), "mfma_utilisation_vs_2.5PF_dense_f16": round(flops_issued / mf["mfma"] / 1e9 / 2500.0, 4),
+                                        "note": "HBM/L2-bound at these block sizes (<= 64 flop per byte); the build itself selects inside k_fused<insert> (exact VALU order) -- hx_index_set_mfma serves the lock-step placement"}
     if iterative:
         passes = (np.arange(n) % iterative["filter_every"] == 0).astype(np.uint8)
         nqi = int(os.environ.get("HX_ITER_QUERIES", "500"))
