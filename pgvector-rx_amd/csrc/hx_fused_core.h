@@ -19,6 +19,9 @@
 #else
 #define FUSED_TIMERS_ON false
 #endif
+#ifndef FUSED_BAR_BEFORE_ROWS
+#define FUSED_BAR_BEFORE_ROWS false   /* true: wait for the visited-set CAS before the row loads of an expansion are issued (the behaviour up to round 2; A/B knob) */
+#endif
 #define FUSED_SLOTS_PER_CU 24u     /* the per-wave spill areas and visited tables are sized for this many resident searches per CU */
 #ifndef FUSED_MINW_SA
 #define FUSED_MINW_SA 4             /* the sorted-array query kernel */

@@ -194,7 +194,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
             if (vcount * 4u > (uint32_t)vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
             if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
-            F_BAR();
+            if constexpr (POSTED || FUSED_BAR_BEFORE_ROWS) F_BAR(); else F_WSYNC();   // the ids are read back by this wave (LDS is in order); no wait for the visited-set CAS still in flight: it is settled after the row loads
             F_TICK(3);
             const float mine = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
             F_TICK(4);
@@ -345,7 +345,7 @@ __device__ void f_search_layer_sa(const FusedParams &p, FusedCtx &cx, uint32_t n
             if (vcount * 4u > (uint32_t)vis_words * 3u) { cx.status = FS_OVERFLOW; break; }
             if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
-            F_BAR();
+            if constexpr (POSTED || FUSED_BAR_BEFORE_ROWS) F_BAR(); else F_WSYNC();   // the ids are read back by this wave (LDS is in order); no wait for the visited-set CAS still in flight: it is settled after the row loads
             F_TICK(3);
             const float mine = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
             F_TICK(4);
