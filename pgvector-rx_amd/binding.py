@@ -510,12 +510,25 @@ class Index:
         self._ck(lib().hx_index_fused_stats(self.h, C.byref(a), C.byref(b)))
         return {"tasks": a.value, "redone": b.value & 0xFFFFFFFF, "max_candidate_heap": b.value >> 32}
 
+    @staticmethod
+    def _pad(cnt, k, *arrays_and_fills):
+        """The ABI defines the first counts_out[q] entries of a row; the rest is set here (-1 / inf / 0), and only for the rows that are short --
+        pre-filling 1.6 MB per 10 000-query call cost 3 % of the bench's step time."""
+        short = np.nonzero(cnt < k)[0]
+        if short.size:
+            tail = np.arange(k)[None, :] >= cnt[short, None]
+            for a, fill in arrays_and_fills:
+                sub = a[short]
+                sub[tail] = fill
+                a[short] = sub
+
     def search(self, nq, ef_search, k):
-        tids = np.full((nq, k), -1, np.int64)
-        d = np.full((nq, k), np.inf, np.float32)
-        el = np.zeros((nq, k), np.uint32)
+        tids = np.empty((nq, k), np.int64)
+        d = np.empty((nq, k), np.float32)
+        el = np.empty((nq, k), np.uint32)
         cnt = np.zeros(nq, np.uint32)
         self._ck(lib().hx_index_search(self.h, nq, ef_search, k, _p(tids), _p(d), _p(el), _p(cnt)))
+        self._pad(cnt, k, (tids, -1), (d, np.inf), (el, 0))
         return tids, d, el, cnt
 
     def search_null(self, ef_search, limit, mode=0, max_scan_tuples=20000, filter_pass=None):
@@ -528,10 +541,11 @@ class Index:
         return tids[:cnt.value], el[:cnt.value]
 
     def search_iterative(self, nq, ef_search, mode, max_scan_tuples, limit, filter_pass=None):
-        tids = np.full((nq, limit), -1, np.int64)
-        d = np.full((nq, limit), np.inf, np.float32)
+        tids = np.empty((nq, limit), np.int64)
+        d = np.empty((nq, limit), np.float32)
         cnt = np.zeros(nq, np.uint32)
         f = None if filter_pass is None else np.ascontiguousarray(filter_pass, np.uint8)
         self._ck(lib().hx_index_search_iterative(self.h, nq, ef_search, mode, max_scan_tuples, limit, _p(f),
                                                  0 if f is None else len(f), _p(tids), _p(d), _p(cnt)))
+        self._pad(cnt, limit, (tids, -1), (d, np.inf))
         return tids, d, cnt
