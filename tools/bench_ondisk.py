@@ -1,0 +1,23 @@
+"""aminsert on the engine (hx_index_insert_ondisk, lock-step placement): rows/s into an index of `base` rows, per batch (= concurrent backends).
+python tools/bench_ondisk.py [base_rows] [insert_rows] [dim]"""
+import json, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+import pgvector_rx_amd as hx
+import bench
+
+base = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+ins = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+dim = int(sys.argv[3]) if len(sys.argv) > 3 else 768
+m, efc = 16, 64
+for b in (10, 256, 2048, 8192):
+    n = base + ins
+    rows, _ = bench.synth(n, dim, "gmm", 1, "cuda")
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n); e.append_device(rows.data_ptr(), n)
+    ix = hx.Index(e, m, efc)
+    levels = hx.draw_levels(n, m, seed=1)
+    ix.insert(0, levels[:base], batch=32768)
+    k = min(ins, max(b * 4, 512))
+    t0 = time.perf_counter(); ix.insert_ondisk(base, levels[base:base + k], tids=np.arange(base, base + k), batch=b); dt = time.perf_counter() - t0
+    print(json.dumps({"base_rows": base, "dim": dim, "m": m, "ef_construction": efc, "concurrent_inserts": b, "rows": k, "rows_per_s": round(k / dt, 1)}), flush=True)
+    ix.close(); e.close(); del rows
