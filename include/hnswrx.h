@@ -148,7 +148,8 @@ int hx_rows_equal(hx_engine *e, uint32_t n_pairs, const uint32_t *a_ids, const u
 int hx_set_timing(hx_engine *e, int enabled);
 int hx_last_kernel_ms(hx_engine *e, float *ms);
 /* Accumulated since the last reset, while timing is enabled: kind 0 = query-vs-rows kernel (units =
- * distances), kind 1 = pair-block kernel (units = pairs), 2 = traversal kernel, 3 = back-link kernels, 4 = MFMA pair kernel (units = pairs). */
+ * distances), kind 1 = pair-block kernel (units = pairs), 2 = traversal kernel, 3 = back-link kernels, 4 = MFMA pair kernel (units = pairs),
+ * 5 = pipelined scans (hx_index_search_submit): units = distances, ms = the UNION of the overlapping launches' busy intervals. */
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset);
 
 /* ------------------------------------------------------------------------------------------------
@@ -277,6 +278,19 @@ int hx_index_profile(const hx_index *ix, double seconds_out[16], int reset);
  * TIDs nearest first with their distances; counts_out[q] = number returned. */
 int hx_index_search(hx_index *ix, uint32_t nq, uint32_t ef_search, uint32_t k,
                     int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out);
+
+/* The same scan, pipelined.  A launch of the traversal kernel ends with a round of searches that no longer fills the chip (one search
+ * long, ~2 ms of a 9 ms launch at 10 000 queries on 1M x 768); a host that has the NEXT batch of queries ready (one backend per connection:
+ * scan.rs:709-876 is called per query, batches arrive continuously) submits it before it collects the previous one, each batch on a slot
+ * (0 .. HX_SCAN_SLOTS-1) with a stream, staging buffers, visited tables and spill areas of its own, and the first round of batch N+1 fills the
+ * CUs the last round of batch N leaves idle.
+ *   hx_index_search_submit: queries = engine query slots first_query .. first_query+nq-1 (hx_set_queries uploads all batches' queries);
+ *                           returns at once (HX_E_STATE if the slot is busy or the index cannot scan on the device: use hx_index_search then).
+ *   hx_index_search_wait:   blocks until that batch is done; outputs as hx_index_search (per query k heap TIDs nearest first).
+ * Results are those of hx_index_search bit for bit.  The index must not be modified between a submit and its wait (mutators return HX_E_STATE). */
+#define HX_SCAN_SLOTS 4
+int hx_index_search_submit(hx_index *ix, uint32_t slot, uint32_t first_query, uint32_t nq, uint32_t ef_search, uint32_t k);
+int hx_index_search_wait(hx_index *ix, uint32_t slot, int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out);
 
 /* Iterative scan (hnsw.iterative_scan = relaxed_order | strict_order, scan.rs:794-875): per query, keeps
  * resuming from the discarded heap until `limit` tuples for which filter_pass[tid] != 0 were produced,

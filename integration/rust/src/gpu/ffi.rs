@@ -127,6 +127,10 @@ extern "C" {
     // scans
     pub fn hx_index_search(ix: *mut hx_index, nq: u32, ef_search: u32, k: u32, tids_out: *mut i64, dist_out: *mut f32,
                            elems_out: *mut u32, counts_out: *mut u32) -> c_int;
+    /// Pipelined scan (include/hnswrx.h): submit the next batch of queries before collecting the previous one; slots 0..HX_SCAN_SLOTS-1.
+    pub fn hx_index_search_submit(ix: *mut hx_index, slot: u32, first_query: u32, nq: u32, ef_search: u32, k: u32) -> c_int;
+    pub fn hx_index_search_wait(ix: *mut hx_index, slot: u32, tids_out: *mut i64, dist_out: *mut f32, elems_out: *mut u32,
+                                counts_out: *mut u32) -> c_int;
     pub fn hx_index_search_iterative(ix: *mut hx_index, nq: u32, ef_search: u32, mode: c_int, max_scan_tuples: i64, limit: u32,
                                      filter_pass: *const u8, n_filter: u64, tids_out: *mut i64, dist_out: *mut f32,
                                      counts_out: *mut u32) -> c_int;

@@ -123,6 +123,8 @@ def lib():
         "hx_index_mfma_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_fused_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "hx_index_search": (i32, [vp, u32, u32, u32, vp, vp, vp, vp]),
+        "hx_index_search_submit": (i32, [vp, u32, u32, u32, u32, u32]),
+        "hx_index_search_wait": (i32, [vp, u32, vp, vp, vp, vp]),
         "hx_index_search_iterative": (i32, [vp, u32, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
         "hx_index_search_null": (i32, [vp, u32, i32, i64, u32, vp, u64, vp, vp, vp]),
         "hx_index_serialize_pages": (i32, [vp, vp, u64, C.POINTER(u64), vp, vp]),
@@ -528,6 +530,23 @@ class Index:
         el = np.empty((nq, k), np.uint32)
         cnt = np.zeros(nq, np.uint32)
         self._ck(lib().hx_index_search(self.h, nq, ef_search, k, _p(tids), _p(d), _p(el), _p(cnt)))
+        self._pad(cnt, k, (tids, -1), (d, np.inf), (el, 0))
+        return tids, d, el, cnt
+
+    def search_submit(self, slot, first_query, nq, ef_search, k):
+        """Pipelined scan: launches the scan of engine query slots [first_query, first_query + nq) on `slot` and returns at once."""
+        self._ck(lib().hx_index_search_submit(self.h, slot, first_query, nq, ef_search, k))
+        self._scan_shape = getattr(self, "_scan_shape", {})
+        self._scan_shape[slot] = (nq, k)
+
+    def search_wait(self, slot):
+        """Results of the scan submitted on `slot`: as search()."""
+        nq, k = self._scan_shape.pop(slot)
+        tids = np.empty((nq, k), np.int64)
+        d = np.empty((nq, k), np.float32)
+        el = np.empty((nq, k), np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        self._ck(lib().hx_index_search_wait(self.h, slot, _p(tids), _p(d), _p(el), _p(cnt)))
         self._pad(cnt, k, (tids, -1), (d, np.inf), (el, 0))
         return tids, d, el, cnt
 

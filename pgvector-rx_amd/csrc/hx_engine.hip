@@ -473,11 +473,23 @@ int hx_destroy(hx_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     HxChannel &c = e->ch;
     HxMirror &mr = e->mirror;
-    void *hp[] = {c.h_req, c.h_res, mr.h_stage, mr.h_io, mr.h_lk, e->grp.h_ctr, e->grp.h, e->bw.h, e->bw.h_ctr};
-    void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries, mr.d_l0_ids, mr.d_l0_d, mr.d_l0_cnt, mr.d_level, mr.d_up_block, mr.d_up_ids, mr.d_up_d, mr.d_up_cnt, mr.d_vis, mr.d_stage, mr.d_io, mr.d_lk, mr.d_pm, mr.d_pm_valid, mr.d_spill,
+    void *hp[] = {c.h_req, c.h_res, mr.h_stage, mr.io.h_io, mr.h_lk, e->grp.h_ctr, e->grp.h, e->bw.h, e->bw.h_ctr};
+    void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries, mr.d_l0_ids, mr.d_l0_d, mr.d_l0_cnt, mr.d_level, mr.d_up_block, mr.d_up_ids, mr.d_up_d, mr.d_up_cnt, mr.io.d_vis, mr.d_stage, mr.io.d_io, mr.d_lk, mr.d_pm, mr.d_pm_valid, mr.io.d_spill,
                   mr.d_disc, mr.d_emask, mr.d_spill_big, mr.d_vis_big, e->grp.d, e->bw.d, e->bw.d_rec, e->d_xl, e->bw.d_wtab, e->bw.d_wt_valid, e->d_mf_norm2};
     for (void *p : hp) if (p) (void)hipHostFree(p);
     for (void *p : dp) if (p) (void)hipFree(p);
+    for (HxFusedIo &io : e->scan_io) {                           // pipelined scan slots: a launch still in flight is drained first
+        if (io.stream) (void)hipStreamSynchronize(io.stream);
+        if (io.h_io) (void)hipHostFree(io.h_io);
+        if (io.d_io) (void)hipFree(io.d_io);
+        if (io.d_vis) (void)hipFree(io.d_vis);
+        if (io.d_spill) (void)hipFree(io.d_spill);
+        if (io.ev0) (void)hipEventDestroy(io.ev0);
+        if (io.ev1) (void)hipEventDestroy(io.ev1);
+        if (io.ev_dep) (void)hipEventDestroy(io.ev_dep);
+        if (io.stream && io.own_stream) (void)hipStreamDestroy(io.stream);
+    }
+    if (e->ev_scan_epoch) (void)hipEventDestroy(e->ev_scan_epoch);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->ev2) (void)hipEventDestroy(e->ev2);
@@ -784,7 +796,8 @@ int hx_last_kernel_ms(hx_engine *e, float *ms) { if (!e || !ms) return HX_E_ARG;
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset)
 {
     if (!e) return HX_E_ARG;
-    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : kind == 2 ? e->stat_fused : kind == 3 ? e->stat_links : e->stat_mfma;
+    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : kind == 2 ? e->stat_fused : kind == 3 ? e->stat_links : kind == 5 ? e->stat_scan : e->stat_mfma;
+    if (kind == 5 && reset) { e->scan_epoch_set = false; e->scan_last_end = 0.0; }
     if (launches) *launches = s.launches;
     if (units) *units = s.units;
     if (ms) *ms = s.ms;

@@ -133,7 +133,15 @@ int hx_engine::mirror_download(uint64_t n_elems, uint64_t n_blocks, uint32_t *l0
     return HX_OK;
 }
 
+// k_fused2 (pooled stream waves) and the sorted-array search are measured-slower / tie-inexact experiments: compiled only with
+// HX_CFLAGS=-DHX_EXPERIMENTS, selected by HX_FUSED2=1 / HX_SORTED_ARRAY=1
+#ifdef HX_EXPERIMENTS
 static int fused2_env_on() { static const int v = getenv("HX_FUSED2") ? atoi(getenv("HX_FUSED2")) : 0; return v; }
+static int sa_env_on() { return getenv("HX_SORTED_ARRAY") ? atoi(getenv("HX_SORTED_ARRAY")) : 0; }
+#else
+static int fused2_env_on() { return 0; }
+static int sa_env_on() { return 0; }
+#endif
 
 // mode 0: ntasks queries -> out_ids/out_d [ntasks][k], out_cnt[ntasks]; mode 1: ntasks inserts -> out_ids/out_d
 // [ntasks][FUSED_MAXL][2m], out_cnt [ntasks][FUSED_MAXL].  status[ntasks].  All host pointers.
@@ -141,8 +149,35 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
                          uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
                          uint64_t counts[2], const HxFusedIter *it, HxFusedView *view, uint32_t roomy, const HxFusedDev *dev)
 {
-    HxMirror &mr = mirror;
     if (ntasks == 0) return HX_OK;
+    HxFusedIo &io = mirror.io;
+    if (!io.stream) { io.stream = stream; io.ev0 = ev0; io.ev1 = ev1; }     // the engine's own stream and events
+    int rc = fused_launch(io, mode, ntasks, q_sel, t_level, ef, k, entry, entry_level, it, roomy, dev);
+    if (rc) return rc;
+    return fused_collect(io, out_ids, out_d, out_cnt, status, counts, view);
+}
+
+// a pipelined scan slot: a stream, events and buffers of its own (created on first use)
+int hx_engine::scan_io_init(uint32_t slot)
+{
+    if (slot >= HX_SCAN_SLOTS) return fail(HX_E_ARG, "scan slot out of range");
+    HxFusedIo &io = scan_io[slot];
+    if (io.stream) return HX_OK;
+    HX_HIP(this, hipSetDevice(device));
+    HX_HIP(this, hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking)); io.own_stream = true;
+    HX_HIP(this, hipEventCreate(&io.ev0)); HX_HIP(this, hipEventCreate(&io.ev1));
+    HX_HIP(this, hipEventCreateWithFlags(&io.ev_dep, hipEventDisableTiming));
+    return HX_OK;
+}
+
+// Everything of a launch up to its asynchronous result copies, on io.stream; nothing here waits for the device.
+int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
+                            uint32_t entry, int entry_level, const HxFusedIter *it, uint32_t roomy, const HxFusedDev *dev)
+{
+    HxMirror &mr = mirror;
+    hipStream_t stream = io.stream;                                  // shadows the engine's: every call below goes to this launch's stream
+    if (io.busy) return fail(HX_E_STATE, "a launch is still in flight on this slot");
+    if (ntasks == 0) return fail(HX_E_ARG, "no tasks");
     if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_ARG, "row too wide for the fused kernel");
     if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
     if (mode == 2 && (!it || !it->emask || !it->out_tix)) return fail(HX_E_ARG, "iterative scan arguments missing");
@@ -162,7 +197,7 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
     // HX_SORTED_ARRAY=1 (opt-in experiment, hx_fused_kernel.h: f_search_layer_sa): first launches of queries search on one sorted array; a query that
     // meets a tie reports FS_OVERFLOW and its retry launch (roomy > 1) uses the heap kernel, which is exact for any input
-    const int sa_env = getenv("HX_SORTED_ARRAY") ? atoi(getenv("HX_SORTED_ARRAY")) : 0;
+    const int sa_env = sa_env_on();
     const bool sa = sa_env && roomy == 1 && mode == 0 && dtype != HX_BIT && ef > 1 && ef <= 256 && !fused2_env_on();
     if (sa) clds = 0;                                            // no candidate heap
     if (mode == 1) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
@@ -220,8 +255,8 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         }
         HX_HIP(this, hipMemcpyAsync(mr.d_emask, it->emask, (size_t)it->n_elems * 2, hipMemcpyHostToDevice, stream));
     }
-    if (!mr.d_spill) HX_HIP(this, hipMalloc((void **)&mr.d_spill, (size_t)256 * FUSED_SLOTS_PER_CU * FUSED_CCAP * 8));
-    uint32_t *vis_ptr = nullptr; void *spill_ptr = mr.d_spill;
+    if (!io.d_spill) HX_HIP(this, hipMalloc((void **)&io.d_spill, (size_t)256 * FUSED_SLOTS_PER_CU * FUSED_CCAP * 8));
+    uint32_t *vis_ptr = nullptr; void *spill_ptr = io.d_spill;
     if (roomy > 1) {   // a retry launch of a few overflowed tasks: private, larger tables sized for exactly this grid
         grid = std::min<uint32_t>(grid, 1024u);
         const size_t need_sp = (size_t)grid * ccap * 8; const uint64_t need_vis = (uint64_t)grid * vis_words;
@@ -229,26 +264,26 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
         if (need_vis > mr.cap_vis_big) { if (mr.d_vis_big) (void)hipFree(mr.d_vis_big); mr.d_vis_big = nullptr; mr.cap_vis_big = 0; HX_HIP(this, hipMalloc((void **)&mr.d_vis_big, need_vis * 4)); mr.cap_vis_big = need_vis; }
         vis_ptr = mr.d_vis_big; spill_ptr = mr.d_spill_big;
     }
-    if (roomy == 1 && (uint64_t)grid * vis_words > mr.cap_vis) {
-        if (mr.d_vis) (void)hipFree(mr.d_vis);
-        mr.d_vis = nullptr; mr.cap_vis = 0;
+    if (roomy == 1 && (uint64_t)grid * vis_words > io.cap_vis) {
+        if (io.d_vis) (void)hipFree(io.d_vis);
+        io.d_vis = nullptr; io.cap_vis = 0;
         const uint64_t n = (uint64_t)(mode == 2 ? grid : 256u * FUSED_SLOTS_PER_CU) * vis_words;
-        HX_HIP(this, hipMalloc((void **)&mr.d_vis, n * 4));
-        mr.cap_vis = n;
+        HX_HIP(this, hipMalloc((void **)&io.d_vis, n * 4));
+        io.cap_vis = n;
     }
     // dev: the neighbour lists go straight into the caller's device records (a batch's exchange buffer); only the statuses come back
     const size_t out_n = dev ? 0 : mode != 1 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;      // mode 2: k = limit
     const size_t cnt_n = dev ? 0 : mode != 1 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
     // device task/in/out buffers (one allocation, reused)
     const size_t need = al16((size_t)ntasks * 4) * 4 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
-    if (need > mr.cap_io) {
-        if (mr.d_io) (void)hipFree(mr.d_io);
-        if (mr.h_io) (void)hipHostFree(mr.h_io);
-        mr.d_io = mr.h_io = nullptr; mr.cap_io = 0;
+    if (need > io.cap_io) {
+        if (io.d_io) (void)hipFree(io.d_io);
+        if (io.h_io) (void)hipHostFree(io.h_io);
+        io.d_io = io.h_io = nullptr; io.cap_io = 0;
         const size_t n = need * 2;
-        HX_HIP(this, hipMalloc((void **)&mr.d_io, n));
-        HX_HIP(this, hipHostMalloc((void **)&mr.h_io, n, hipHostMallocDefault));
-        mr.cap_io = n;
+        HX_HIP(this, hipMalloc((void **)&io.d_io, n));
+        HX_HIP(this, hipHostMalloc((void **)&io.h_io, n, hipHostMallocDefault));
+        io.cap_io = n;
     }
     size_t o = 0;
     const size_t o_ctr = o; o += 256;
@@ -261,72 +296,100 @@ int hx_engine::fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const
     const size_t o_ids = o; o += al16(out_n * 4);
     const size_t o_d = o; o += al16(out_n * 4);
     const size_t o_tix = o; o += al16(out_n * 4);
-    memset(mr.h_io + o_ctr, 0, 256);
-    memcpy(mr.h_io + o_q, q_sel, (size_t)ntasks * 4);
-    if (t_level) memcpy(mr.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(mr.h_io + o_lv, 0, (size_t)ntasks * 4);
-    if (dev && dev->h_slots) memcpy(mr.h_io + o_slot, dev->h_slots, (size_t)ntasks * 4);
-    HX_HIP(this, hipMemcpyAsync(mr.d_io, mr.h_io, in_bytes, hipMemcpyHostToDevice, stream));
+    memset(io.h_io + o_ctr, 0, 256);
+    memcpy(io.h_io + o_q, q_sel, (size_t)ntasks * 4);
+    if (t_level) memcpy(io.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(io.h_io + o_lv, 0, (size_t)ntasks * 4);
+    if (dev && dev->h_slots) memcpy(io.h_io + o_slot, dev->h_slots, (size_t)ntasks * 4);
+    HX_HIP(this, hipMemcpyAsync(io.d_io, io.h_io, in_bytes, hipMemcpyHostToDevice, stream));
     FusedParams p;
     p.rows = d_rows; p.queries = d_queries; p.pitch = (uint32_t)pitch; p.nch = (uint32_t)((pitch + 1023) / 1024); p.n_rows = n_rows;
     p.l0_ids = mr.d_l0_ids; p.l0_cnt = mr.d_l0_cnt; p.level = mr.d_level; p.up_block = mr.d_up_block; p.up_ids = mr.d_up_ids; p.up_cnt = mr.d_up_cnt;
     p.l0_d = mr.d_l0_d; p.up_d = mr.d_up_d;
     p.m = mr.m; p.entry = entry; p.entry_level = entry_level;
-    p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(mr.d_io + o_q); p.t_level = (const int32_t *)(mr.d_io + o_lv);
+    p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(io.d_io + o_q); p.t_level = (const int32_t *)(io.d_io + o_lv);
     p.ef = ef; p.k = k; p.ccap = ccap; p.clds = clds;
-    p.iter_mode = 0; p.limit = k; p.max_tuples = 0; p.emask = nullptr; p.disc = nullptr; p.disc_stride = 0; p.disc_lds = disc_lds; p.out_tix = (uint32_t *)(mr.d_io + o_tix);
+    p.iter_mode = 0; p.limit = k; p.max_tuples = 0; p.emask = nullptr; p.disc = nullptr; p.disc_stride = 0; p.disc_lds = disc_lds; p.out_tix = (uint32_t *)(io.d_io + o_tix);
     if (mode == 2) { p.iter_mode = (uint32_t)it->iter_mode; p.max_tuples = it->max_tuples; p.emask = mr.d_emask; p.disc = (unsigned long long *)mr.d_disc; p.disc_stride = (uint32_t)disc_stride; }
     p.spill = (uint2 *)spill_ptr; p.spill_stride = ccap;
     { const char *dv = getenv("HX_F_DBG"); p.fdbg = dv ? (uint32_t)atoi(dv) : 0u; }
     p.sa = sa ? 1u : 0u;
-    p.vis = vis_ptr ? vis_ptr : mr.d_vis; p.vis_words = vis_words;
-    p.next_task = (uint32_t *)(mr.d_io + o_ctr);
-    p.n_dist = (unsigned long long *)(mr.d_io + o_ctr + 8);
-    p.out_ids = (uint32_t *)(mr.d_io + o_ids); p.out_d = (float *)(mr.d_io + o_d); p.out_cnt = (uint32_t *)(mr.d_io + o_cnt);
-    p.status = (uint32_t *)(mr.d_io + o_st);
+    p.vis = vis_ptr ? vis_ptr : io.d_vis; p.vis_words = vis_words;
+    p.next_task = (uint32_t *)(io.d_io + o_ctr);
+    p.n_dist = (unsigned long long *)(io.d_io + o_ctr + 8);
+    p.out_ids = (uint32_t *)(io.d_io + o_ids); p.out_d = (float *)(io.d_io + o_d); p.out_cnt = (uint32_t *)(io.d_io + o_cnt);
+    p.status = (uint32_t *)(io.d_io + o_st);
     p.o_cst = FUSED_MAXL; p.o_lst = FUSED_MAXL * 2 * mr.m; p.t_oslot = nullptr;
     p.wtab = nullptr; p.wt_size = 0; p.wt_slot0 = 0; p.wt_valid = nullptr;
     if (dev && dev->d_wtab) { p.wtab = (uint2 *)dev->d_wtab; p.wt_size = dev->wt_size; p.wt_slot0 = dev->wt_slot0; p.wt_valid = dev->d_wt_valid; }
     if (dev) {   // record = cnt[FUSED_MAXL] | ids[FUSED_MAXL][2m] | d[FUSED_MAXL][2m]  (hx_batch.hip reads the same layout)
         p.out_cnt = dev->d_rec; p.out_ids = dev->d_rec + FUSED_MAXL; p.out_d = (float *)(dev->d_rec + FUSED_MAXL + FUSED_MAXL * 2 * mr.m);
         p.o_cst = p.o_lst = dev->rec_words;
-        if (dev->h_slots) p.t_oslot = (const uint32_t *)(mr.d_io + o_slot);
+        if (dev->h_slots) p.t_oslot = (const uint32_t *)(io.d_io + o_slot);
     }
-    if (timing) HX_HIP(this, hipEventRecord(ev0, stream));
+    if (timing && io.own_stream && !scan_epoch_set) {   // time zero of the pipelined scans' busy-time union
+        if (!ev_scan_epoch) HX_HIP(this, hipEventCreate(&ev_scan_epoch));
+        HX_HIP(this, hipEventRecord(ev_scan_epoch, this->stream)); HX_HIP(this, hipEventSynchronize(ev_scan_epoch));
+        scan_epoch_set = true; scan_last_end = 0.0;
+    }
+    if (timing) HX_HIP(this, hipEventRecord(io.ev0, stream));
     hipError_t ls = hipSuccess;
+    fused_stream = stream;
+#ifdef HX_EXPERIMENTS
     if (nc2) ls = dtype == HX_F32 ? hx_launch_fused2_f32(this, metric, p, grid, nc2, slot_bytes, mode)
                : dtype == HX_F16 ? hx_launch_fused2_f16(this, metric, p, grid, nc2, slot_bytes, mode) : hx_launch_fused2_bit(this, metric, p, grid, nc2, slot_bytes, mode);
-    else ls = dtype == HX_F32 ? hx_launch_fused_f32(this, metric, p, grid, lds, mode)
+    else
+#endif
+    ls = dtype == HX_F32 ? hx_launch_fused_f32(this, metric, p, grid, lds, mode)
             : dtype == HX_F16 ? hx_launch_fused_f16(this, metric, p, grid, lds, mode) : hx_launch_fused_bit(this, metric, p, grid, lds, mode);
     HX_HIP(this, ls);
-    if (timing) HX_HIP(this, hipEventRecord(ev1, stream));
-    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_ctr, mr.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));
-    HX_HIP(this, hipMemcpyAsync(mr.h_io + o_st, mr.d_io + o_st, (dev ? o_cnt : mode == 2 ? o : o_tix) - o_st, hipMemcpyDeviceToHost, stream));
-    HX_HIP(this, hipStreamSynchronize(stream));
+    if (timing) HX_HIP(this, hipEventRecord(io.ev1, stream));
+    HX_HIP(this, hipMemcpyAsync(io.h_io + o_ctr, io.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(io.h_io + o_st, io.d_io + o_st, (dev ? o_cnt : mode == 2 ? o : o_tix) - o_st, hipMemcpyDeviceToHost, stream));
+    io.busy = true; io.mode = mode; io.ntasks = ntasks; io.roomy = roomy; io.timed = timing; io.it = it; io.has_dev = dev != nullptr;
+    io.o_ctr = o_ctr; io.o_st = o_st; io.o_cnt = o_cnt; io.o_ids = o_ids; io.o_d = o_d; io.o_tix = o_tix; io.out_n = out_n; io.cnt_n = cnt_n;
+    return HX_OK;
+}
+
+// waits for the launch in flight on `io` and hands its results over (view: read in place from the pinned staging buffer)
+int hx_engine::fused_collect(HxFusedIo &io, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status, uint64_t counts[2], HxFusedView *view)
+{
+    if (!io.busy) return fail(HX_E_STATE, "no launch in flight on this slot");
+    io.busy = false;
+    const int mode = io.mode; const uint32_t ntasks = io.ntasks, roomy = io.roomy; const bool dev = io.has_dev; const HxFusedIter *it = io.it;
+    const size_t o_ctr = io.o_ctr, o_st = io.o_st, o_cnt = io.o_cnt, o_ids = io.o_ids, o_d = io.o_d, o_tix = io.o_tix, out_n = io.out_n, cnt_n = io.cnt_n;
+    HX_HIP(this, hipSetDevice(device));
+    HX_HIP(this, hipStreamSynchronize(io.stream));
     if (roomy == 1 && mode != 2) {   // test hook: pretend every k-th task overflowed, so that the roomy retry path is exercised
         const char *fv = getenv("HX_FORCE_OVERFLOW_MOD"); const uint32_t k = fv ? (uint32_t)atoi(fv) : 0u;
-        if (k) for (uint32_t t = 0; t < ntasks; t += k) ((uint32_t *)(mr.h_io + o_st))[t] = FS_OVERFLOW;
+        if (k) for (uint32_t t = 0; t < ntasks; t += k) ((uint32_t *)(io.h_io + o_st))[t] = FS_OVERFLOW;
     }
-    if (dev) { if (status) memcpy(status, mr.h_io + o_st, (size_t)ntasks * 4); }
+    if (dev) { if (status) memcpy(status, io.h_io + o_st, (size_t)ntasks * 4); }
     else if (view) {   // the caller reads the pinned staging buffer in place
-        view->status = (const uint32_t *)(mr.h_io + o_st); view->cnt = (const uint32_t *)(mr.h_io + o_cnt);
-        view->ids = (const uint32_t *)(mr.h_io + o_ids); view->d = (const float *)(mr.h_io + o_d);
+        view->status = (const uint32_t *)(io.h_io + o_st); view->cnt = (const uint32_t *)(io.h_io + o_cnt);
+        view->ids = (const uint32_t *)(io.h_io + o_ids); view->d = (const float *)(io.h_io + o_d);
     } else {
-        memcpy(status, mr.h_io + o_st, (size_t)ntasks * 4);
-        memcpy(out_cnt, mr.h_io + o_cnt, cnt_n * 4);
-        memcpy(out_ids, mr.h_io + o_ids, out_n * 4);
-        memcpy(out_d, mr.h_io + o_d, out_n * 4);
+        memcpy(status, io.h_io + o_st, (size_t)ntasks * 4);
+        memcpy(out_cnt, io.h_io + o_cnt, cnt_n * 4);
+        memcpy(out_ids, io.h_io + o_ids, out_n * 4);
+        memcpy(out_d, io.h_io + o_d, out_n * 4);
     }
-    if (mode == 2) memcpy(it->out_tix, mr.h_io + o_tix, out_n * 4);
-    unsigned long long nd[17]; memcpy(nd, mr.h_io + o_ctr + 8, 136);
+    if (mode == 2) memcpy(it->out_tix, io.h_io + o_tix, out_n * 4);
+    unsigned long long nd[17]; memcpy(nd, io.h_io + o_ctr + 8, 136);
     if (getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4) && !FUSED_TIMERS_ON) { static bool once = false; if (!once) { once = true; fprintf(stderr, "[hx] HX_F_DBG=4: this library was built without -DFUSED_TIMERS (HX_CFLAGS=-DFUSED_TIMERS python pgvector-rx_amd/build.py --force)\n"); } }
     if (FUSED_TIMERS_ON && getenv("HX_F_DBG") && (atoi(getenv("HX_F_DBG")) & 4))
         fprintf(stderr, "[hx] k_fused mode %d tasks %u: shader-clock ticks (s_memtime) summed over waves: pop %llu list %llu visited %llu compact %llu dist %llu settle+filter %llu replay %llu; expansions %llu pushes %llu; inside dist: issue %llu wait %llu math %llu reduce %llu; select phase %llu\n",
                 mode, ntasks, nd[3], nd[4], nd[5], nd[6], nd[7], nd[8], nd[9], nd[10], nd[11], nd[12], nd[13], nd[14], nd[15], nd[16]);
     if (counts) { counts[0] = nd[0]; counts[1] = nd[1]; }
     if (nd[2] > fused_cmax) fused_cmax = nd[2];
-    if (timing) {
-        float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev0, ev1));
+    if (io.timed) {
+        float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, io.ev0, io.ev1));
         last_ms = ms; stat_fused.launches++; stat_fused.units += nd[0] + nd[1]; stat_fused.ms += ms;
+        if (io.own_stream && scan_epoch_set) {
+            float t_end = 0.f; HX_HIP(this, hipEventElapsedTime(&t_end, ev_scan_epoch, io.ev1));
+            const double b = (double)t_end, a = std::max(b - (double)ms, scan_last_end);
+            stat_scan.launches++; stat_scan.units += nd[0]; if (b > a) stat_scan.ms += b - a;
+            if (b > scan_last_end) scan_last_end = b;
+        }
     }
     return HX_OK;
 }

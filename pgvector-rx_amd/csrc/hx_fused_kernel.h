@@ -262,6 +262,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
     F_BAR();
 }
 
+#ifdef HX_EXPERIMENTS
 // search_layer / search_layer_disk on ONE sorted array (the `SA` kernels; SURVEY 8 row a1 / a4, same results as f_search_layer).
 //
 // Without ties the two heaps of Algorithm 2 carry redundant state: every element of C was pushed to W at the same moment (mod.rs:236-241), an element
@@ -406,6 +407,8 @@ __device__ void f_search_layer_sa(const FusedParams &p, FusedCtx &cx, uint32_t n
     F_BAR();
 }
 
+#endif  // HX_EXPERIMENTS
+
 // stable sort of the W heap's internal array into EP: ascending (build, mod.rs:248-254) or descending (scan.rs:441-446);
 // rank sort: ties keep their order in W's array, exactly what a stable sort of that array does
 __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
@@ -486,12 +489,14 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
         const int stop_above = MODE == 1 ? new_level : 0;
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
+#ifdef HX_EXPERIMENTS
             if constexpr (SA) {
                 f_search_layer_sa<OP, LPR, POSTED>(p, cx, n_ep, 1u, lc);
                 if (cx.CTL[1] > 0) { const uint2 best = cx.W[0]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); n_ep = 1; }
                 else if (MODE != 1) { n_ep = 0; break; }
                 continue;
             }
+#endif
             f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, 1u, lc, MODE != 1);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
@@ -557,6 +562,7 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
         } else if (MODE == 0) {
             uint32_t cnt = 0;
             if (cx.status == FS_OK && n_ep > 0) {
+#ifdef HX_EXPERIMENTS
                 if constexpr (SA) {
                     f_search_layer_sa<OP, LPR, POSTED>(p, cx, n_ep, p.ef, 0);                        // scan.rs:515-528; W comes out ascending
                     const uint32_t wl = cx.CTL[1];
@@ -565,7 +571,9 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
                         const uint2 v = cx.W[i];
                         p.out_ids[(size_t)t * p.k + i] = v.y; p.out_d[(size_t)t * p.k + i] = fh_d(v);
                     }
-                } else {
+                } else
+#endif
+                {
                 f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, true);                                        // nearest LAST
@@ -681,6 +689,7 @@ k_fused(const FusedParams p_in)
     f_worker<OP, MODE, LPR, false, SA>(p, lds, lds, blockIdx.x, threadIdx.x);
 }
 
+#ifdef HX_EXPERIMENTS
 // k_fused2: nc control waves (one search each, f_worker<POSTED>) + stream waves (f_stream_loop) per 1024-thread workgroup; see hx_fused_core.h
 template <class OP, int MODE>
 __global__ void __launch_bounds__(1024, 1)
@@ -704,6 +713,8 @@ k_fused2(const FusedParams p_in, const uint32_t nc, const uint32_t slot_bytes)
     }
 }
 
+#endif  // HX_EXPERIMENTS
+
 template <class OP, int MODE, int LPR, bool SA = false>
 static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds)
 {
@@ -718,10 +729,11 @@ static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid
         if (!once) { once = true; int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k_fused<OP, MODE, LPR, SA>, 64, lds);
             fprintf(stderr, "[hx] k_fused<mode %d, %d lanes/row, sorted-array %d>: dynamic LDS %zu B, grid %u, occupancy API says %d blocks/CU\n", MODE, LPR, (int)SA, lds, grid, nb); }
     }
-    hipLaunchKernelGGL((k_fused<OP, MODE, LPR, SA>), dim3(grid), dim3(64), lds, e->stream, p);
+    hipLaunchKernelGGL((k_fused<OP, MODE, LPR, SA>), dim3(grid), dim3(64), lds, e->fused_stream ? e->fused_stream : e->stream, p);
     return hipGetLastError();
 }
 
+#ifdef HX_EXPERIMENTS
 template <class OP, int MODE>
 static hipError_t launch_fused2(hx_engine *e, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes)
 {
@@ -731,7 +743,7 @@ static hipError_t launch_fused2(hx_engine *e, const FusedParams &p, uint32_t gri
         if (s != hipSuccess) return s;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_fused2<OP, MODE>), dim3(grid), dim3(1024), (size_t)nc * slot_bytes + 64, e->stream, p, nc, slot_bytes);
+    hipLaunchKernelGGL((k_fused2<OP, MODE>), dim3(grid), dim3(1024), (size_t)nc * slot_bytes + 64, e->fused_stream ? e->fused_stream : e->stream, p, nc, slot_bytes);
     return hipGetLastError();
 }
 template <class OP>
@@ -740,11 +752,15 @@ static hipError_t launch_fused2_mode(hx_engine *e, const FusedParams &p, uint32_
     return mode == 0 ? launch_fused2<OP, 0>(e, p, grid, nc, slot_bytes) : launch_fused2<OP, 1>(e, p, grid, nc, slot_bytes);
 }
 
+#endif  // HX_EXPERIMENTS
+
 template <class OP, int LPR>
 static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
 {
     if (mode == 2) return launch_fused<OP, 2, LPR>(e, p, grid, lds);
+#ifdef HX_EXPERIMENTS
     if constexpr (OP::sorted_array_ok) { if (p.sa && mode == 0) return launch_fused<OP, 0, LPR, true>(e, p, grid, lds); }
+#endif
     return mode == 0 ? launch_fused<OP, 0, LPR>(e, p, grid, lds) : launch_fused<OP, 1, LPR>(e, p, grid, lds);
 }
 template <class OP>

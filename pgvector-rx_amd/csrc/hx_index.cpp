@@ -800,6 +800,8 @@ struct hx_index {
     std::vector<std::pair<uint32_t, int>> dirty;               // (element, layer) lists the device mirror has not seen yet
     uint32_t mirror_elems = 0;
     uint64_t fused_tasks = 0, fused_redo = 0;
+    struct ScanSlot { bool busy = false; uint32_t first = 0, nq = 0, ef = 0, k = 0; } scan_slot[HX_SCAN_SLOTS];   // pipelined scans in flight (hx_index_search_submit)
+    uint32_t scans_in_flight = 0;
     double prof[16] = {0};   // seconds: [0] advance, [1] compact, [2] fill, [3] dist launch+wait, [4] pair launch+wait, [5] rounds
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
@@ -1058,6 +1060,7 @@ int hx_index_set_threads(hx_index *ix, int n_threads)
 // ---- lists are all-gathered between the stages -- pgvector-rx_amd/dist_build.py) --------------------------------
 int hx_index_batch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (!ix) return HX_E_ARG;
     hx_index::Timer t_bb(ix->prof[12]);
     if (b == 0 || !levels || !tids) return ix->fail(HX_E_ARG, "empty batch or NULL argument");
@@ -1468,6 +1471,7 @@ uint64_t hx_index_dbatch_list_record_bytes(const hx_index *ix) { return ix ? (ui
 
 int hx_index_dbatch_begin(hx_index *ix, uint64_t first_row, uint32_t b, const int32_t *levels, const int64_t *tids)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (!ix) return HX_E_ARG;
     hx_index::Timer t_bb(ix->prof[12]);
     if (b == 0 || !levels || !tids) return ix->fail(HX_E_ARG, "empty batch or NULL argument");
@@ -1636,6 +1640,7 @@ int hx_index_dbatch_end(hx_index *ix, uint32_t *elem_out)
 int hx_index_insert(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids,
                     uint32_t batch, uint32_t *elem_out)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (!ix) return HX_E_ARG;
     if (n == 0) return HX_OK;
     hx_index::Timer t_all(ix->prof[10]);
@@ -1703,6 +1708,7 @@ void write_neighbor_update(hx_index *ix, uint32_t n, int layer, uint32_t new_id,
 
 int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids, uint32_t batch, uint32_t *elem_out)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (!ix) return HX_E_ARG;
     if (n == 0) return HX_OK;
     if (!levels || !tids) return ix->fail(HX_E_ARG, "NULL argument");
@@ -1802,6 +1808,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
 // reference does; batch > 1: that many repair searches run in lock-step against the same state of the graph.
 int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uint32_t batch, uint64_t *n_deleted_out, uint64_t *n_repaired_out)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (!ix || (!dead_tids && n_dead)) return HX_E_ARG;
     Graph &g = ix->g;
     if (ix->bs.open) return ix->fail(HX_E_STATE, "a staged batch is open");
@@ -1898,6 +1905,7 @@ int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uin
 // vacuum does (highest remaining level) -- so that device scans never return or traverse a tuple whose slot now holds something else.
 int hx_index_invalidate(hx_index *ix, uint32_t n, const uint32_t *blkno, const uint16_t *offno, const uint8_t *versions, uint32_t *n_dropped_out)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (!ix || (n && (!blkno || !offno))) return HX_E_ARG;
     if (n_dropped_out) *n_dropped_out = 0;
     Graph &g = ix->g;
@@ -1987,6 +1995,7 @@ int hx_index_export_layer(const hx_index *ix, int layer, uint32_t first, uint32_
 
 int hx_index_set_neighbors(hx_index *ix, uint32_t elem, int layer, uint32_t count, const uint32_t *ids, const float *dist)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (ix) { int rc0 = ix->ensure_host_lists(); if (rc0) return rc0; }
     if (!ix || elem >= ix->g.size()) return HX_E_ARG;
     Graph &g = ix->g;
@@ -2036,6 +2045,101 @@ int hx_index_counters(const hx_index *ix, uint64_t counters_out[8])
     return HX_OK;
 }
 
+// the scans `todo` (indices into the caller's output arrays; engine query slot = q0 + index) on the lock-step host driver
+static int lockstep_scan(hx_index *ix, const std::vector<uint32_t> &todo, uint32_t q0, uint32_t ef_search, int mode, int64_t max_scan_tuples, uint32_t limit,
+                         const uint8_t *filter, uint64_t n_filter, int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out)
+{
+    const uint32_t nt = (uint32_t)todo.size();
+    std::vector<std::unique_ptr<QueryTask>> &qs = ix->query_pool; std::vector<LsTask *> tasks(nt);
+    while (qs.size() < nt) qs.emplace_back(new QueryTask());
+    for (uint32_t qi = 0; qi < nt; qi++) {
+        const uint32_t q = todo[qi];
+        QueryTask &t = *qs[qi];
+        t.st = QueryTask::Q_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req(); t.tuples = 0; t.previous_distance = -HUGE_VAL;
+        t.out_tid.clear(); t.out_d.clear(); t.out_elem.clear(); t.discarded.clear(); t.results.clear();
+        t.g = &ix->g; t.slot = q0 + q; t.ef_search = ef_search; t.mode = mode; t.max_scan_tuples = max_scan_tuples; t.limit = limit;
+        t.filter = filter; t.n_filter = n_filter;
+        tasks[qi] = &t;
+    }
+    int rc = ix->run_lockstep(tasks);
+    if (rc) return rc;
+    for (uint32_t qi = 0; qi < nt; qi++) {
+        const uint32_t q = todo[qi];
+        QueryTask &t = *qs[qi];
+        const uint32_t c = (uint32_t)t.out_tid.size();
+        counts_out[q] = c;
+        for (uint32_t k = 0; k < c; k++) {
+            tids_out[(size_t)q * limit + k] = t.out_tid[k];
+            if (dist_out) dist_out[(size_t)q * limit + k] = t.out_d[k];
+            if (elems_out) elems_out[(size_t)q * limit + k] = t.out_elem[k];
+        }
+        ix->counters[4] += t.n_dist;
+    }
+    return HX_OK;
+}
+
+
+// amgettuple's expansion of a device scan's results (per query: every heap TID of each element, nearest first, scan.rs:794-875) and the
+// one retry of overflowed queries on the device with roomier tables; queries that still fail are appended to `todo` (lock-step driver).
+// q0: engine query slot of the view's first query (pipelined scans address a window of the uploaded queries)
+static int finish_device_scan(hx_index *ix, const HxFusedView &v, uint32_t q0, uint32_t nq, uint32_t ef_search, uint32_t limit,
+                          int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out, std::vector<uint32_t> &todo)
+{
+    const Graph &g = ix->g;
+    const uint32_t ke = std::min<uint32_t>(limit, ef_search);
+    int rc;
+    uint64_t cnts[2] = {0, 0};
+    const uint32_t *status = v.status, *ocnt = v.cnt, *oids = v.ids; const float *od = v.d;
+    const double t_exp0 = hx_index::now_s();
+    ix->pool->parallel_for((nq + 1023) / 1024, [&](size_t ci) {
+        for (uint32_t q = (uint32_t)ci * 1024; q < std::min<uint32_t>(nq, (uint32_t)ci * 1024 + 1024); q++) {
+            if (status[q] != 0) continue;
+            if (q + 1 < nq) for (uint32_t i = 0; i < ocnt[q + 1] && i < ke; i++) {      // the heap TIDs of the next query's elements: random host reads
+                const uint32_t eln = oids[(size_t)(q + 1) * ke + i]; __builtin_prefetch(&g.tids[eln]); __builtin_prefetch(&g.ntids[eln]);
+            }
+            uint32_t c = 0;                                  // amgettuple: every heap TID of each element, nearest first (scan.rs:794-875)
+            for (uint32_t i = 0; i < ocnt[q] && c < limit; i++) {
+                const uint32_t el = oids[(size_t)q * ke + i];
+                for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
+                    tids_out[(size_t)q * limit + c] = g.tids[el][t];
+                    if (dist_out) dist_out[(size_t)q * limit + c] = od[(size_t)q * ke + i];
+                    if (elems_out) elems_out[(size_t)q * limit + c] = el;
+                    c++;
+                }
+            }
+            counts_out[q] = c;
+        }
+    });
+    ix->prof[15] += hx_index::now_s() - t_exp0;
+    std::vector<uint32_t> again;                             // overflowed queries: one more try on the device with roomier tables
+    for (uint32_t q = 0; q < nq; q++) { if (status[q] == 1) again.push_back(q); else if (status[q] != 0) todo.push_back(q); }
+    if (!again.empty()) {
+        const uint32_t na = (uint32_t)again.size();
+        std::vector<uint32_t> q2(na);
+        for (uint32_t k = 0; k < na; k++) q2[k] = HX_QUERY_SLOT | (q0 + again[k]);
+        HxFusedView v2;
+        if ((rc = ix->e->fused_run(0, na, q2.data(), nullptr, ef_search, ke, (uint32_t)g.entry, g.level[g.entry],
+                                   nullptr, nullptr, nullptr, nullptr, cnts, nullptr, &v2, 8))) return ix->fail(rc, ix->e->err);
+        ix->counters[4] += cnts[0];
+        for (uint32_t k = 0; k < na; k++) {
+            const uint32_t q = again[k];
+            if (v2.status[k] != 0) { todo.push_back(q); continue; }
+            uint32_t c = 0;
+            for (uint32_t i = 0; i < v2.cnt[k] && c < limit; i++) {
+                const uint32_t el = v2.ids[(size_t)k * ke + i];
+                for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
+                    tids_out[(size_t)q * limit + c] = g.tids[el][t];
+                    if (dist_out) dist_out[(size_t)q * limit + c] = v2.d[(size_t)k * ke + i];
+                    if (elems_out) elems_out[(size_t)q * limit + c] = el;
+                    c++;
+                }
+            }
+            counts_out[q] = c;
+        }
+    }
+    return HX_OK;
+}
+
 static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, int64_t max_scan_tuples, uint32_t limit,
                        const uint8_t *filter, uint64_t n_filter, int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out)
 {
@@ -2061,54 +2165,7 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
                                    nullptr, nullptr, nullptr, nullptr, cnts, nullptr, &v))) return ix->fail(rc, ix->e->err);
         ix->prof[6] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         ix->counters[4] += cnts[0];
-        const uint32_t *status = v.status, *ocnt = v.cnt, *oids = v.ids; const float *od = v.d;
-        const double t_exp0 = hx_index::now_s();
-        ix->pool->parallel_for((nq + 1023) / 1024, [&](size_t ci) {
-            for (uint32_t q = (uint32_t)ci * 1024; q < std::min<uint32_t>(nq, (uint32_t)ci * 1024 + 1024); q++) {
-                if (status[q] != 0) continue;
-                if (q + 1 < nq) for (uint32_t i = 0; i < ocnt[q + 1] && i < ke; i++) {      // the heap TIDs of the next query's elements: random host reads
-                    const uint32_t eln = oids[(size_t)(q + 1) * ke + i]; __builtin_prefetch(&g.tids[eln]); __builtin_prefetch(&g.ntids[eln]);
-                }
-                uint32_t c = 0;                                  // amgettuple: every heap TID of each element, nearest first (scan.rs:794-875)
-                for (uint32_t i = 0; i < ocnt[q] && c < limit; i++) {
-                    const uint32_t el = oids[(size_t)q * ke + i];
-                    for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
-                        tids_out[(size_t)q * limit + c] = g.tids[el][t];
-                        if (dist_out) dist_out[(size_t)q * limit + c] = od[(size_t)q * ke + i];
-                        if (elems_out) elems_out[(size_t)q * limit + c] = el;
-                        c++;
-                    }
-                }
-                counts_out[q] = c;
-            }
-        });
-        ix->prof[15] += hx_index::now_s() - t_exp0;
-        std::vector<uint32_t> again;                             // overflowed queries: one more try on the device with roomier tables
-        for (uint32_t q = 0; q < nq; q++) { if (status[q] == 1) again.push_back(q); else if (status[q] != 0) todo.push_back(q); }
-        if (!again.empty()) {
-            const uint32_t na = (uint32_t)again.size();
-            std::vector<uint32_t> q2(na);
-            for (uint32_t k = 0; k < na; k++) q2[k] = HX_QUERY_SLOT | again[k];
-            HxFusedView v2;
-            if ((rc = ix->e->fused_run(0, na, q2.data(), nullptr, ef_search, ke, (uint32_t)g.entry, g.level[g.entry],
-                                       nullptr, nullptr, nullptr, nullptr, cnts, nullptr, &v2, 8))) return ix->fail(rc, ix->e->err);
-            ix->counters[4] += cnts[0];
-            for (uint32_t k = 0; k < na; k++) {
-                const uint32_t q = again[k];
-                if (v2.status[k] != 0) { todo.push_back(q); continue; }
-                uint32_t c = 0;
-                for (uint32_t i = 0; i < v2.cnt[k] && c < limit; i++) {
-                    const uint32_t el = v2.ids[(size_t)k * ke + i];
-                    for (int t = (int)g.ntids[el] - 1; t >= 0 && c < limit; t--) {
-                        tids_out[(size_t)q * limit + c] = g.tids[el][t];
-                        if (dist_out) dist_out[(size_t)q * limit + c] = v2.d[(size_t)k * ke + i];
-                        if (elems_out) elems_out[(size_t)q * limit + c] = el;
-                        c++;
-                    }
-                }
-                counts_out[q] = c;
-            }
-        }
+        if ((rc = finish_device_scan(ix, v, 0, nq, ef_search, limit, tids_out, dist_out, elems_out, counts_out, todo))) return rc;
         ix->fused_tasks += nq; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
     } else if (mode != 0 && ix->fused_scan_ok() && ix->g.entry >= 0 && limit <= 4096) {
@@ -2164,39 +2221,62 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
     } else {
         for (uint32_t q = 0; q < nq; q++) todo.push_back(q);
     }
-    const uint32_t nt = (uint32_t)todo.size();
-    std::vector<std::unique_ptr<QueryTask>> &qs = ix->query_pool; std::vector<LsTask *> tasks(nt);
-    while (qs.size() < nt) qs.emplace_back(new QueryTask());
-    for (uint32_t qi = 0; qi < nt; qi++) {
-        const uint32_t q = todo[qi];
-        QueryTask &t = *qs[qi];
-        t.st = QueryTask::Q_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req(); t.tuples = 0; t.previous_distance = -HUGE_VAL;
-        t.out_tid.clear(); t.out_d.clear(); t.out_elem.clear(); t.discarded.clear(); t.results.clear();
-        t.g = &ix->g; t.slot = q; t.ef_search = ef_search; t.mode = mode; t.max_scan_tuples = max_scan_tuples; t.limit = limit;
-        t.filter = filter; t.n_filter = n_filter;
-        tasks[qi] = &t;
-    }
-    int rc = ix->run_lockstep(tasks);
-    if (rc) return rc;
-    for (uint32_t qi = 0; qi < nt; qi++) {
-        const uint32_t q = todo[qi];
-        QueryTask &t = *qs[qi];
-        const uint32_t c = (uint32_t)t.out_tid.size();
-        counts_out[q] = c;
-        for (uint32_t k = 0; k < c; k++) {
-            tids_out[(size_t)q * limit + k] = t.out_tid[k];
-            if (dist_out) dist_out[(size_t)q * limit + k] = t.out_d[k];
-            if (elems_out) elems_out[(size_t)q * limit + k] = t.out_elem[k];
-        }
-        ix->counters[4] += t.n_dist;
-    }
-    return HX_OK;
+    return lockstep_scan(ix, todo, 0, ef_search, mode, max_scan_tuples, limit, filter, n_filter, tids_out, dist_out, elems_out, counts_out);
 }
 
 int hx_index_search(hx_index *ix, uint32_t nq, uint32_t ef_search, uint32_t k,
                     int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out)
 {
     return search_impl(ix, nq, ef_search, 0, 0, k, nullptr, 0, tids_out, dist_out, elems_out, counts_out);
+}
+
+int hx_index_search_submit(hx_index *ix, uint32_t slot, uint32_t first_query, uint32_t nq, uint32_t ef_search, uint32_t k)
+{
+    if (!ix) return HX_E_ARG;
+    if (slot >= HX_SCAN_SLOTS) return ix->fail(HX_E_ARG, "scan slot out of range");
+    if (nq == 0 || k == 0) return ix->fail(HX_E_ARG, "nq and k must be positive");
+    if (ef_search < 1 || ef_search > 1000) return ix->fail(HX_E_ARG, "hnsw.ef_search must be between 1 and 1000");   // options.rs:156-166
+    if ((uint64_t)first_query + nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
+    hx_index::ScanSlot &ss = ix->scan_slot[slot];
+    if (ss.busy) return ix->fail(HX_E_STATE, "scan slot busy: hx_index_search_wait first");
+    if (!ix->fused_scan_ok() || ix->g.entry < 0) return ix->fail(HX_E_STATE, "this index does not scan on the device (empty, sparsevec or hx_index_set_fused(0)): use hx_index_search");
+    int rc;
+    if (ix->scans_in_flight == 0) { if ((rc = ix->sync_mirror())) return rc; }
+    else if (ix->g.size() != ix->mirror_elems || !ix->dirty.empty()) return ix->fail(HX_E_STATE, "the index was modified while a scan is in flight");
+    hx_engine *e = ix->e;
+    if ((rc = e->scan_io_init(slot))) return ix->fail(rc, e->err);
+    HxFusedIo &io = e->scan_io[slot];
+    // the mirror and the queries were written on the engine's stream: order this slot's stream behind it
+    if (hipEventRecord(io.ev_dep, e->stream) != hipSuccess || hipStreamWaitEvent(io.stream, io.ev_dep, 0) != hipSuccess) return ix->fail(HX_E_HIP, "stream dependency");
+    const Graph &g = ix->g;
+    const uint32_t ke = std::min<uint32_t>(k, ef_search);
+    std::vector<uint32_t> qsel(nq);
+    for (uint32_t q = 0; q < nq; q++) qsel[q] = HX_QUERY_SLOT | (first_query + q);
+    if ((rc = e->fused_launch(io, 0, nq, qsel.data(), nullptr, ef_search, ke, (uint32_t)g.entry, g.level[g.entry], nullptr, 1, nullptr))) return ix->fail(rc, e->err);
+    ss.busy = true; ss.first = first_query; ss.nq = nq; ss.ef = ef_search; ss.k = k;
+    ix->scans_in_flight++;
+    return HX_OK;
+}
+
+int hx_index_search_wait(hx_index *ix, uint32_t slot, int64_t *tids_out, float *dist_out, uint32_t *elems_out, uint32_t *counts_out)
+{
+    if (!ix) return HX_E_ARG;
+    if (slot >= HX_SCAN_SLOTS) return ix->fail(HX_E_ARG, "scan slot out of range");
+    if (!tids_out || !counts_out) return ix->fail(HX_E_ARG, "NULL argument");
+    hx_index::ScanSlot &ss = ix->scan_slot[slot];
+    if (!ss.busy) return ix->fail(HX_E_STATE, "nothing submitted on this scan slot");
+    hx_engine *e = ix->e;
+    HxFusedView v; uint64_t cnts[2] = {0, 0};
+    ss.busy = false; ix->scans_in_flight--;
+    int rc = e->fused_collect(e->scan_io[slot], nullptr, nullptr, nullptr, nullptr, cnts, &v);
+    if (rc) return ix->fail(rc, e->err);
+    ix->counters[4] += cnts[0];
+    std::vector<uint32_t> todo;
+    if ((rc = finish_device_scan(ix, v, ss.first, ss.nq, ss.ef, ss.k, tids_out, dist_out, elems_out, counts_out, todo))) return rc;
+    ix->fused_tasks += ss.nq; ix->fused_redo += todo.size();
+    if (todo.empty()) return HX_OK;
+    // a query that outgrew even the roomy tables: the lock-step driver (still on the GPU kernels) serves it from its engine query slot
+    return lockstep_scan(ix, todo, ss.first, ss.ef, 0, 0, ss.k, nullptr, 0, tids_out, dist_out, elems_out, counts_out);
 }
 
 int hx_index_search_iterative(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, int64_t max_scan_tuples,
@@ -2398,6 +2478,7 @@ inline TidRef get_tid(const uint8_t *p) { return TidRef{(get16(p) << 16) | get16
 int hx_index_load_pages(hx_index *ix, const uint8_t *pages, uint64_t n_pages, uint32_t *elem_blkno_out, uint16_t *elem_offno_out,
                         uint64_t cap_elems, uint64_t *n_elems_out)
 {
+    if (ix && ix->scans_in_flight) return ix->fail(HX_E_STATE, "a pipelined scan is in flight: hx_index_search_wait first");
     if (!ix || !pages || !n_elems_out) return HX_E_ARG;
     Graph &g = ix->g; hx_engine *e = ix->e;
     if (e->dtype == HX_SPARSE) return ix->fail(HX_E_ARG, "no page image for sparsevec");

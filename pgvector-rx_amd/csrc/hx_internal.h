@@ -38,6 +38,30 @@ struct HxChannel {
 
 struct HxKernelStat { uint64_t launches = 0, units = 0; double ms = 0.0; };
 
+// arguments of an iterative scan on the device (k_fused MODE 2)
+struct HxFusedIter {
+    int iter_mode = 1; long long max_tuples = 0;       // 1 relaxed_order, 2 strict_order; hnsw.max_scan_tuples
+    const uint16_t *emask = nullptr; uint64_t n_elems = 0;   // per element: bits 0-9 heap TIDs that pass the filter, bits 12-15 number of heap TIDs
+    uint32_t *out_tix = nullptr;                       // [ntasks][limit]: which heap TID of out_ids' element
+};
+// zero-copy view of a fused launch's results in its pinned staging buffer (valid until the next launch on the same HxFusedIo)
+struct HxFusedView { const uint32_t *ids = nullptr, *cnt = nullptr, *status = nullptr; const float *d = nullptr; };
+struct HxFusedDev;
+// Everything ONE k_fused launch in flight owns: its stream and events, the pinned + device staging of tasks and results, the per-workgroup visited
+// tables and candidate-heap spill areas, and what fused_collect needs to finish it.  The engine's synchronous launches use mirror.io on the engine
+// stream; pipelined scans (hx_index_search_submit / _wait) use scan_io[slot], each on a stream of its own, so that the first round of launch N+1
+// fills the CUs the last round of launch N leaves idle.
+struct HxFusedIo {
+    hipStream_t stream = nullptr; bool own_stream = false; hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
+    uint8_t *h_io = nullptr, *d_io = nullptr; size_t cap_io = 0;
+    uint32_t *d_vis = nullptr; uint64_t cap_vis = 0;
+    void *d_spill = nullptr;                 // candidate-heap spill areas of the fused kernel's workgroups
+    // the launch in flight (fused_launch -> fused_collect)
+    bool busy = false; int mode = 0; uint32_t ntasks = 0, roomy = 1; bool timed = false;
+    size_t o_ctr = 0, o_st = 0, o_cnt = 0, o_ids = 0, o_d = 0, o_tix = 0, out_n = 0, cnt_n = 0;
+    const HxFusedIter *it = nullptr; bool has_dev = false;
+};
+
 // device copy of the graph (neighbour ids only) + scratch of the fused traversal kernel (hx_fused.inc.h)
 struct HxMirror {
     uint32_t m = 0; uint64_t cap = 0, cap_blocks = 0;
@@ -45,17 +69,12 @@ struct HxMirror {
     uint32_t *d_up_block = nullptr, *d_up_ids = nullptr; float *d_up_d = nullptr; uint16_t *d_up_cnt = nullptr;
     uint8_t *h_lk = nullptr, *d_lk = nullptr; size_t cap_lk = 0;
     float *d_pm = nullptr; uint8_t *d_pm_valid = nullptr; uint64_t cap_pm = 0;   // resident pair matrices of the layer-0 lists
-    uint32_t *d_vis = nullptr; uint64_t cap_vis = 0;
-    void *d_spill = nullptr;                 // candidate-heap spill areas of the fused kernel's workgroups
+    HxFusedIo io;                            // task / result staging, visited tables and spill areas of the synchronous fused_run launches (engine stream)
     void *d_spill_big = nullptr; size_t cap_spill_big = 0; uint32_t *d_vis_big = nullptr; uint64_t cap_vis_big = 0;   // tables of a retry launch (fused_run roomy > 1)
     void *d_disc = nullptr; size_t cap_disc = 0;             // `discarded` heaps of iterative scans (k_fused MODE 2)
     uint16_t *d_emask = nullptr; uint64_t cap_emask = 0;     // per-element heap-TID filter masks of the current iterative scan
     uint8_t *h_stage = nullptr, *d_stage = nullptr; size_t cap_stage = 0;
-    uint8_t *h_io = nullptr, *d_io = nullptr; size_t cap_io = 0;
 };
-
-// zero-copy view of a fused_run's results in the engine's pinned staging buffer (valid until the next fused_run)
-struct HxFusedView { const uint32_t *ids = nullptr, *cnt = nullptr, *status = nullptr; const float *d = nullptr; };
 
 // insert-mode results written straight into device records (a batch's exchange buffer, hx_batch.hip): record r =
 // cnt[HX_FUSED_MAXL] | ids[HX_FUSED_MAXL][2m] | d[HX_FUSED_MAXL][2m], rec_words 32-bit words apart; task t fills record h_slots[t] (nullptr: t)
@@ -85,22 +104,19 @@ int hx_group_run(hx_engine *e, uint32_t n_ops, uint32_t hub_min, HxGroupWork &w,
 int hx_group_ops(hx_engine *e, uint32_t n_ops, const unsigned long long *h_keys, const uint32_t *h_new, const float *h_d, uint32_t hub_min,
                  HxGroupWork &w, uint32_t counters_out[5], bool want_fill = false);
 
-// arguments of an iterative scan on the device (k_fused MODE 2)
-struct HxFusedIter {
-    int iter_mode = 1; long long max_tuples = 0;       // 1 relaxed_order, 2 strict_order; hnsw.max_scan_tuples
-    const uint16_t *emask = nullptr; uint64_t n_elems = 0;   // per element: bits 0-9 heap TIDs that pass the filter, bits 12-15 number of heap TIDs
-    uint32_t *out_tix = nullptr;                       // [ntasks][limit]: which heap TID of out_ids' element
-};
-
 struct hx_engine {
     int device = 0, dtype = 0, metric = 0, dim = 0;
     uint64_t row_bytes = 0, pitch = 0, capacity = 0, n_rows = 0;
     uint8_t *d_rows = nullptr;
     uint8_t *d_queries = nullptr; uint32_t cap_queries = 0, n_queries = 0;
     hipStream_t stream = nullptr;
+    hipStream_t fused_stream = nullptr;   // the stream the k_fused launchers use (set by fused_launch: the engine's, or a pipelined scan slot's)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timing = false; float last_ms = 0.f;
     HxKernelStat stat_dist, stat_pair, stat_fused, stat_links, stat_mfma;
+    // pipelined scans: launches overlap, so their busy time is the UNION of the launches' [start, end] intervals (HIP events of each slot's stream,
+    // measured from ev_scan_epoch on the engine's stream); stat_scan.ms = that union
+    HxKernelStat stat_scan; hipEvent_t ev_scan_epoch = nullptr; bool scan_epoch_set = false; double scan_last_end = 0.0;
     hipEvent_t ev4 = nullptr, ev5 = nullptr;
     // |row|^2 of halfvec rows for the MFMA band (hx_mfma.hip)
     float *d_mf_norm2 = nullptr; uint64_t mf_cap = 0, mf_norm_rows = 0; std::vector<float> h_mf_norm2;
@@ -144,6 +160,12 @@ struct hx_engine {
     int links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
                   const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs,
                   bool want_lists = true);   // false: the updated lists stay in the mirror only (the host pulls them when it needs them)
+    // fused_run = fused_launch (everything up to the asynchronous result copies, on io.stream) + fused_collect (stream sync, results, counters)
+    HxFusedIo scan_io[HX_SCAN_SLOTS];
+    int scan_io_init(uint32_t slot);
+    int fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
+                     uint32_t entry, int entry_level, const HxFusedIter *it, uint32_t roomy, const HxFusedDev *dev);
+    int fused_collect(HxFusedIo &io, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status, uint64_t counts[2], HxFusedView *view);
     int fused_run(int mode, uint32_t ntasks, const uint32_t *q_sel, const int32_t *t_level, uint32_t ef, uint32_t k,
                   uint32_t entry, int entry_level, uint32_t *out_ids, float *out_d, uint32_t *out_cnt, uint32_t *status,
                   uint64_t counts[2], const HxFusedIter *it = nullptr, HxFusedView *view = nullptr, uint32_t roomy = 1, const HxFusedDev *dev = nullptr);   // roomy > 1: retry of overflowed tasks with that many times the visited table and candidate heap

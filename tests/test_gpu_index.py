@@ -814,3 +814,40 @@ def test_m_above_16_stays_on_the_device(dtype, metric, dim, n, m, efc, batch):
         assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=40, limit=10)]
     ix.close()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,metric,dim", [(hx.F32, hx.L2SQ, 200), (hx.F16, hx.NEG_IP, 40), (hx.BIT, hx.HAMMING, 96)])
+def test_pipelined_scans_equal_the_plain_scan(dtype, metric, dim, monkeypatch):
+    """hx_index_search_submit / _wait: several batches of queries in flight on slots with streams and tables of their own return, batch by
+    batch, exactly what hx_index_search returns for the same query slots (and the oracle's answers); a busy slot, an empty slot and a
+    mutation while a scan is in flight are refused.  The second pass forces overflow retries inside the waits."""
+    rng = np.random.default_rng(dim)
+    n, m, efc, nq, k, efs = 4000, 12, 48, 96, 10, 64
+    rows, qs = make_rows(dtype, n, dim, rng), make_rows(dtype, 3 * nq, dim, rng)
+    levels = hx.draw_levels(n, m, seed=21)
+    e, ix, _, o, _ = build_both(dtype, metric, dim, rows, levels, m, efc, 256)
+    e.set_queries(qs)
+    ref = ix.search(3 * nq, efs, k)
+    for force in (None, "5"):
+        if force:
+            monkeypatch.setenv("HX_FORCE_OVERFLOW_MOD", force)
+        ix.search_submit(0, 0, nq, efs, k)
+        ix.search_submit(1, nq, nq, efs, k)
+        with pytest.raises(hx.HxError):
+            ix.search_submit(1, 2 * nq, nq, efs, k)                     # slot busy
+        with pytest.raises(hx.HxError):
+            ix.insert(0, levels[:1], batch=1)                           # mutation while scans are in flight
+        got0 = ix.search_wait(0)
+        ix.search_submit(0, 2 * nq, nq, efs, k)                          # slot 0 again while slot 1 is still in flight
+        got1 = ix.search_wait(1)
+        got2 = ix.search_wait(0)
+        with pytest.raises(hx.HxError):
+            ix.search_wait(0)                                           # nothing submitted
+        for b, got in enumerate((got0, got1, got2)):
+            for a, r in zip(got, ref):
+                assert np.array_equal(a, r[b * nq:(b + 1) * nq]), (force, b)
+    for q in range(0, 3 * nq, 7):
+        assert ref[0][q, :ref[3][q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=efs, limit=k)]
+    ix.close()
+    e.close()
