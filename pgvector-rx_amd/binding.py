@@ -541,6 +541,8 @@ class Index:
 
     def search_wait(self, slot):
         """Results of the scan submitted on `slot`: as search()."""
+        if slot not in getattr(self, "_scan_shape", {}):
+            raise HxError(-6, "nothing submitted on this scan slot")
         nq, k = self._scan_shape.pop(slot)
         tids = np.empty((nq, k), np.int64)
         d = np.empty((nq, k), np.float32)
