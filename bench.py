@@ -100,33 +100,14 @@ def recall_at_k(tids, cnt, gt, k):
     return hit / (gt.shape[0] * k)
 
 
-class Comm:
-    """The process group the build's collectives run on (dist_build.py only needs these four calls)."""
-
-    def __init__(self, dist, group, backend):
-        self.dist, self.group, self.backend = dist, group, backend
-
-    def get_world_size(self):
-        return self.dist.get_world_size(self.group)
-
-    def get_rank(self):
-        return self.dist.get_rank(self.group)
-
-    def all_gather_into_tensor(self, out, inp):
-        return self.dist.all_gather_into_tensor(out, inp, group=self.group)
-
-    def all_reduce(self, t, op=None):
-        return self.dist.all_reduce(t, op=op or self.dist.ReduceOp.SUM, group=self.group)
-
-    def barrier(self):
-        return self.dist.barrier(group=self.group)
-
-
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (fresh children, before this process makes any
-    GPU call -- a process that touched the GPU must never be re-executed) and pass rank 0's JSON line through."""
+    GPU call -- a process that touched the GPU must never be re-executed) and pass rank 0's JSON line through.  Watchdog: every child is
+    polled; the first one that exits non-zero (or the overall deadline, HX_BENCH_RANK_TIMEOUT seconds) takes the others down with it and
+    this process exits non-zero -- no rank is left waiting for a dead peer inside a collective."""
     import socket
     import subprocess
+    import tempfile
     visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
     if not a.share_gpu and visible < a.gpus:
         print("bench.py: --gpus %d but only %d GPU(s) visible" % (a.gpus, visible), file=sys.stderr, flush=True)
@@ -135,17 +116,44 @@ def launch_ranks(a):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    deadline = time.monotonic() + float(os.environ.get("HX_BENCH_RANK_TIMEOUT", "3000"))
+    out0 = tempfile.TemporaryFile()
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    bad = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        failed = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed:
+            bad = "rank %d exited with code %d" % failed[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            bad = "deadline of HX_BENCH_RANK_TIMEOUT seconds passed"
+            break
+        time.sleep(0.2)
+    if bad:
+        for p in procs:                           # exactly the children started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        print("bench.py: %s; the other ranks were stopped" % bad, file=sys.stderr, flush=True)
+        raise SystemExit(1)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    raise SystemExit(max(abs(rc) for rc in rcs))
+    raise SystemExit(0)
 
 
 def main():
@@ -178,35 +186,13 @@ def run(a, json_fd):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
+    xdev = torch.device("cpu")                   # where the data-path collectives' tensors live
+    from importlib import import_module
+    dbm = import_module("pgvector-rx_amd.dist_build")
     if world > 1:
-        import datetime
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # gloo first: rendezvous, timing reductions, and the place where the ranks AGREE on the data-path backend (a rank that
-        # failed to bring RCCL up must not leave its peers waiting inside an RCCL collective)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        comm = Comm(dist, dist.group.WORLD, "gloo")
-        if a.dist_backend == "nccl":
-            ok, grp, why = 1, None, ""
-            try:   # RCCL over xGMI
-                try:
-                    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
-                except TypeError:
-                    grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
-                probe = torch.ones(1, device=dev)
-                dist.all_reduce(probe, group=grp)
-                torch.cuda.synchronize()
-                ok = int(probe.item() == world)
-            except Exception as ex:   # noqa: BLE001
-                ok, why = 0, (str(ex).splitlines()[0] if str(ex) else type(ex).__name__)
-            flag = torch.tensor([ok], dtype=torch.int64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                comm = Comm(dist, grp, "nccl")
-            else:
-                if not ok:
-                    print("bench.py: rank %d could not bring up the nccl (RCCL) backend (%s); every rank uses gloo" % (rank, why), file=sys.stderr, flush=True)
-                a.dist_backend = "gloo"
-    xdev = dev if (comm is not None and comm.backend == "nccl") else torch.device("cpu")     # where the data-path collectives' tensors live
+        # gloo first (explicit timeout), then RCCL for the data path with the ranks agreeing over gloo at every step (dist_build.bring_up)
+        comm, xdev = dbm.bring_up(rank, world, dev, want=a.dist_backend, log=lambda m: print("bench.py: " + m, file=sys.stderr, flush=True))
+        a.dist_backend = comm.backend
 
     def barrier():
         if world > 1:
@@ -234,8 +220,6 @@ def run(a, json_fd):
     barrier()
     t0 = time.perf_counter()
     if world > 1:
-        from importlib import import_module
-        dbm = import_module("pgvector-rx_amd.dist_build")
         dbm.insert_sharded(ix, 0, levels, eff_batch, comm, xdev, gpu=dev)
         dist_stages = {k: round(v, 3) for k, v in dbm.STAGE_SECONDS.items()}
     else:

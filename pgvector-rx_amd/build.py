@@ -61,11 +61,32 @@ def stale():
     return any(os.path.getmtime(f) > t for f in deps)
 
 
+def _flags_changed():
+    """The objects were compiled with other extra flags (HX_CFLAGS, e.g. -DFUSED_TIMERS or -DHX_EXPERIMENTS) than this call asks for."""
+    try:
+        return open(os.path.join(OBJ, ".flags")).read() != os.environ.get("HX_CFLAGS", "")
+    except OSError:
+        return os.path.isdir(OBJ) and any(f.endswith(".o") for f in os.listdir(OBJ)) and bool(os.environ.get("HX_CFLAGS", ""))
+
+
 def build(force=False, verbose=False):
-    if os.environ.get("HX_LIB") or (not force and not stale()):
+    if os.environ.get("HX_LIB") or (not force and not stale() and not _flags_changed()):
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    # several rank processes import the package at once (bench.py --gpus N, tests/test_dist_gpu.py): one of them builds, the rest wait
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not stale() and not _flags_changed():
+                return LIB
+            return _build_locked(force or _flags_changed(), verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("HX_CFLAGS", "").split()
     todo = [s for s, d in _sources().items() if force or _tu_stale(s, d)]
 
@@ -81,6 +102,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    with open(os.path.join(OBJ, ".flags"), "w") as f:
+        f.write(os.environ.get("HX_CFLAGS", ""))
     return LIB
 
 

@@ -162,7 +162,7 @@ __global__ void k_import_recs(const uint32_t *__restrict__ xr, uint32_t xw, uint
     const uint32_t target = r[0], layer = r[1], c = r[2], lm0 = 2u * mp.m;
     if (layer == 0) {
         if (lane < c) { mp.l0_ids[(size_t)target * lm0 + lane] = r[3 + lane]; mp.l0_d[(size_t)target * lm0 + lane] = __builtin_bit_cast(float, r[3 + lm0 + lane]); }
-        if (lane == 0) mp.l0_cnt[target] = (uint16_t)c;
+        if (lane == 0) { mp.l0_cnt[target] = (uint16_t)c; if (mp.pm_valid) mp.pm_valid[target] = 0; }   // a list another rank pruned: this rank's cached pair matrix of it is stale (as k_mirror_lists does for host-written lists)
     } else {
         const uint32_t blk = mp.up_block[target] + layer - 1u;
         if (lane < c) { mp.up_ids[(size_t)blk * mp.m + lane] = r[3 + lane]; mp.up_d[(size_t)blk * mp.m + lane] = __builtin_bit_cast(float, r[3 + lm0 + lane]); }

@@ -28,6 +28,76 @@ import torch
 STAGE_SECONDS = {}      # wall time per stage of the last insert_sharded call (rank-local, for bench.py's report)
 
 
+class Comm:
+    """The process group the build's collectives run on (insert_sharded only needs these calls)."""
+
+    def __init__(self, dist, group, backend):
+        self.dist, self.group, self.backend = dist, group, backend
+
+    def get_world_size(self):
+        return self.dist.get_world_size(self.group)
+
+    def get_rank(self):
+        return self.dist.get_rank(self.group)
+
+    def all_gather_into_tensor(self, out, inp):
+        return self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_reduce(self, t, op=None):
+        return self.dist.all_reduce(t, op=op or self.dist.ReduceOp.SUM, group=self.group)
+
+    def barrier(self):
+        return self.dist.barrier(group=self.group)
+
+
+def bring_up(rank, world, dev, want="nccl", gloo_timeout_s=300, nccl_timeout_s=120, log=None):
+    """Process groups of a multi-rank build: gloo first (rendezvous, timing reductions, and the place where the ranks AGREE on the
+    data-path backend), then -- want == "nccl" -- an RCCL group for the data path.  The ranks agree over gloo that every one of them
+    CREATED its RCCL group before any of them issues an RCCL collective, and agree again on the probe's result, so a rank that cannot
+    bring RCCL up never leaves its peers inside an RCCL collective: all of them fall back to gloo together.  Every group has an explicit
+    timeout (a rank that died takes its peers out in minutes, not in gloo's default half hour; the launcher's watchdog is faster still).
+    Returns (Comm, device the data-path collectives want their tensors on)."""
+    import datetime
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=gloo_timeout_s))
+    comm = Comm(dist, dist.group.WORLD, "gloo")
+    if want != "nccl":
+        return comm, torch.device("cpu")
+
+    def agree(ok):
+        flag = torch.tensor([int(ok)], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    grp, why = None, ""
+    try:   # RCCL over xGMI
+        try:
+            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=nccl_timeout_s), device_id=dev)
+        except TypeError:
+            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=nccl_timeout_s))
+    except Exception as ex:   # noqa: BLE001
+        why = str(ex).splitlines()[0] if str(ex) else type(ex).__name__
+    created = agree(grp is not None)
+    ok = False
+    if created:
+        try:
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe, group=grp)
+            torch.cuda.synchronize(dev)
+            ok = int(probe.item()) == world
+        except Exception as ex:   # noqa: BLE001
+            why = str(ex).splitlines()[0] if str(ex) else type(ex).__name__
+        ok = agree(ok)
+    if ok:
+        return Comm(dist, grp, "nccl"), dev
+    if log and why:
+        log("rank %d could not bring up the nccl (RCCL) backend (%s); every rank uses gloo" % (rank, why))
+    return comm, torch.device("cpu")
+
+
 def _t(name, t0):
     STAGE_SECONDS[name] = STAGE_SECONDS.get(name, 0.0) + time.perf_counter() - t0
     return time.perf_counter()
@@ -115,10 +185,12 @@ def _device_batch(ix, first_row, levels, tids, dist, device, gpu, world, rank):
     return out
 
 
-def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_shard=256, size_fn=None, gpu=None):
+def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_shard=256, size_fn=None, gpu=None, shard_single_rank=False):
     """hx_index_insert for rows [first_row, first_row + len(levels)) with every batch shared by the ranks.
     `ix` exposes the staged batch API of binding.Index (tests drive this with a stand-in object and gloo).
-    gpu: torch device of this rank's engine; given, batches the device kernels serve exchange device buffers."""
+    gpu: torch device of this rank's engine; given, batches the device kernels serve exchange device buffers.
+    shard_single_rank: a world of ONE rank still takes the sharded stages (the one-GPU rehearsal of the RCCL path: group bring-up,
+    all_gather_into_tensor on device buffers and the stream hand-offs run exactly as they do at 8 ranks)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     levels = np.ascontiguousarray(levels, np.int32)
     n = len(levels)
@@ -129,7 +201,7 @@ def insert_sharded(ix, first_row, levels, batch, dist, device, tids=None, min_sh
     while done < n:
         size = ix.size
         b = min(batch, n - done, max(1, size // 8))           # same ramp-up rule as hx_index_insert
-        if ix.entry < 0 or b < min_shard or world == 1:
+        if ix.entry < 0 or b < min_shard or (world == 1 and not shard_single_rank):
             # replicated: every rank performs the identical single-GPU step
             t0 = time.perf_counter()
             elems[done:done + b] = ix.insert(first_row + done, levels[done:done + b], tids[done:done + b], batch=b)

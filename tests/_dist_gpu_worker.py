@@ -44,6 +44,9 @@ class OneRank:
 
 def main():
     n, dim, m, efc, batch, dt, metric, fmt = (int(x) for x in sys.argv[1:9])
+    tail = int(sys.argv[9]) if len(sys.argv) > 9 else 0          # rows inserted by a second, REPLICATED insert_sharded call after the sharded batches
+    backend = sys.argv[10] if len(sys.argv) > 10 else "gloo"     # "nccl": RCCL data path brought up exactly as bench.py does (dist_build.bring_up)
+    shard_one = len(sys.argv) > 11 and sys.argv[11] == "1"       # a world of one rank still runs the sharded stages
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     rng = np.random.default_rng(123)
@@ -56,20 +59,26 @@ def main():
     rows[n // 2] = rows[7]                 # a duplicate of an old row, and a pair of identical rows inside one batch
     rows[n // 2 + 5] = rows[n // 2 + 3]
     levels = hx.draw_levels(n, m, seed=5)
-    if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        d = dist
+    gpu = torch.device("cuda", 0)
+    xdev = torch.device("cpu")
+    used = "none"
+    if world > 1 or backend == "nccl":
+        torch.cuda.set_device(gpu)
+        d, xdev = db.bring_up(rank, world, gpu, want=backend, log=lambda msg: print(msg, flush=True))
+        used = d.backend
     else:
         d = OneRank
-    gpu = torch.device("cuda", 0)
     e = hx.Engine(dt, metric, dim, n, device=0)
     e.append(rows)
     ix = hx.Index(e, m, efc)
-    elems = db.insert_sharded(ix, 0, levels, batch, d, torch.device("cpu"), min_shard=16, gpu=gpu if fmt else None)
+    head = n - tail
+    elems = db.insert_sharded(ix, 0, levels[:head], batch, d, xdev, min_shard=16, gpu=gpu if fmt else None, shard_single_rank=shard_one)
     stages = dict(db.STAGE_SECONDS)
-    print("DIGEST %s size=%d elems=%s device_batches=%d fused_redone=%d" % (
-        graph_digest(ix, n), ix.size, hashlib.sha256(elems.tobytes()).hexdigest()[:16], int(stages.get("device_batches", 0)), ix.fused_stats()["redone"]), flush=True)
-    if world > 1:
+    if tail:   # a small later insert on the same index: below min_shard, so every rank performs it redundantly ON ITS OWN replica of the graph
+        elems = np.concatenate([elems, db.insert_sharded(ix, head, levels[head:], batch, d, xdev, min_shard=1 << 30, gpu=gpu if fmt else None)])
+    print("DIGEST %s size=%d elems=%s device_batches=%d fused_redone=%d backend=%s" % (
+        graph_digest(ix, n), ix.size, hashlib.sha256(elems.tobytes()).hexdigest()[:16], int(stages.get("device_batches", 0)), ix.fused_stats()["redone"], used), flush=True)
+    if world > 1 or backend == "nccl":
         dist.barrier()
         dist.destroy_process_group()
     ix.close()

@@ -34,7 +34,7 @@ def run_world(world, args):
     for p in procs:
         o, _ = p.communicate(timeout=150)
         assert p.returncode == 0, o
-        outs.append(re.search(r"DIGEST (\w+) size=(\d+) elems=(\w+) device_batches=(\d+) fused_redone=(\d+)", o).groups())
+        outs.append(re.search(r"DIGEST (\w+) size=(\d+) elems=(\w+) device_batches=(\d+) fused_redone=(\d+) backend=(\w+)", o).groups())
     return outs
 
 
@@ -50,3 +50,30 @@ def test_multi_process_build_equals_single_process(world, fmt, shape):
     if fmt:
         assert all(int(o[3]) > 0 for o in outs)          # the device-record exchange was the one exercised
     assert all(int(o[4]) == 0 for o in outs)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_replicated_step_after_sharded_batches(world):
+    """A schedule that ENDS in replicated steps after sharded device batches (a later small insert on the same index): lists that other ranks
+    pruned arrived through k_import_recs, so this rank's resident pair matrices of them are stale and must have been invalidated -- otherwise
+    the replicated prunes read wrong pair distances, differently on every rank, and the replicas diverge silently.  m = 16 is the shape that
+    keeps pair matrices resident; the hubs of the ramp-up are the lists every later step prunes again."""
+    shape = [6000, 24, 16, 64, 512, hx.F32, hx.L2SQ, 1]
+    single = run_world(1, shape + [700])[0]
+    outs = run_world(world, shape + [700])
+    assert all(int(o[1]) == 6000 for o in outs)
+    assert all(o[0] == single[0] and o[2] == single[2] for o in outs), (single, outs)
+    assert all(int(o[3]) > 0 for o in outs)
+
+
+def test_rccl_path_with_one_rank():
+    """The RCCL branch end to end on the one GPU of this box: an nccl process group of world size 1 brought up exactly as bench.py does
+    (dist_build.bring_up: gloo rendezvous, RCCL group, agreement, probe all_reduce), and insert_sharded forced through the device-batch
+    stages -- all_gather_into_tensor on device buffers over RCCL, the torch-stream <-> engine-stream hand-offs, the pruned-list export and
+    import calls -- so that none of it runs for the first time in the driver's 8-GPU job.  The graph must equal the plain single-process build."""
+    shape = [4000, 48, 16, 64, 512, hx.F32, hx.L2SQ, 1]
+    single = run_world(1, shape)[0]
+    got = run_world(1, shape + [0, "nccl", 1])[0]
+    assert got[5] == "nccl", got                      # RCCL came up; a silent fall-back to gloo would hide the branch again
+    assert int(got[3]) > 0                            # device batches took the sharded stages
+    assert got[0] == single[0] and got[2] == single[2] and int(got[1]) == 4000
