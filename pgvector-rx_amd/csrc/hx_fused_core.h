@@ -59,10 +59,14 @@ struct FusedParams {
     const uint16_t *emask;                        // per element: bits 0-9 = which of its heap TIDs pass the filter, bits 12-15 = number of heap TIDs
     unsigned long long *disc; uint32_t disc_stride, disc_lds;   // per-workgroup tail of the `discarded` heap (entries), its LDS head
     uint32_t *out_tix;                            // which heap TID of the element each output is
-    float *dsc;                                   // 64 floats of LDS scratch for the short-row distance path (set inside the kernels)
     uint32_t sa;                                  // 1: searches with ef > 1 run on one sorted array (f_search_layer_sa); ties are redone by the heap kernel
     uint32_t fdbg;                                // experiments (HX_F_DBG): 1 no pre-filter, 4 phase timers into n_dist[3..7]
 };
+
+// The traversal kernels read their parameter block IN PLACE from the kernarg segment (constant address space: scalar loads), through a
+// pointer the compiler cannot see through (k_fused launders it): a field is then s_load-ed where it is used -- hoisted out of a loop only when
+// the loop always reads it -- instead of all ~60 dwords being loaded at kernel entry and held live (or spilled) to the end.
+typedef const __attribute__((address_space(4))) FusedParams KParams;
 
 // one translation unit per element type holds the k_fused instantiations (hx_fused_f32.hip / _f16.hip / _bit.hip)
 hipError_t hx_launch_fused_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
@@ -71,6 +75,11 @@ hipError_t hx_launch_fused_bit(hx_engine *e, int metric, const FusedParams &p, u
 hipError_t hx_launch_fused2_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
 hipError_t hx_launch_fused2_f16(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
 hipError_t hx_launch_fused2_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
+
+// what the query-vs-rows helpers below need: the row store and 64 floats of LDS scratch for the short-row path.  Kept apart from FusedParams
+// so that the kernel's parameters stay an immutable kernel argument (fields are s_load-ed from the kernarg segment where they are used instead of
+// the whole struct being held live in scalar registers -- it was copied to a mutable local for the sake of `dsc`, and spilled)
+struct FRows { const uint8_t *rows; uint32_t pitch, nch; float *dsc; };
 
 struct FHeapItem { float d; uint32_t id; };
 __device__ __forceinline__ uint2 fh_pack(float d, uint32_t id) { return make_uint2(__builtin_bit_cast(unsigned int, d), id); }
@@ -298,6 +307,7 @@ __device__ __forceinline__ bool wt_lookup(const uint2 *tab, uint32_t mask, uint3
 }
 
 struct FusedCtx {
+    FRows fr;
     uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
     GStore DS; lds_uint2 *DP, *WS; uint32_t *LV; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
@@ -309,7 +319,7 @@ struct FusedCtx {
 };
 
 // parks one vector (row or query slot) in LDS, chunk-major: bytes [c*1024 + 16*lane, +16); zero past the pitch
-__device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+__device__ __forceinline__ void f_park(const FRows &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
 {
     for (uint32_t c = 0; c < p.nch; c++) {
         const uint32_t off = c * 1024u + lane * 16u;
@@ -321,7 +331,7 @@ __device__ __forceinline__ void f_park(const FusedParams &p, const uint8_t *src,
 }
 
 // f_park for code that runs in ONE wave of a multi-wave workgroup (no workgroup barrier)
-__device__ __forceinline__ void f_park_w(const FusedParams &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+__device__ __forceinline__ void f_park_w(const FRows &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
 {
     for (uint32_t c = 0; c < p.nch; c++) {
         const uint32_t off = c * 1024u + lane * 16u;
@@ -335,7 +345,7 @@ __device__ __forceinline__ void f_park_w(const FusedParams &p, const uint8_t *sr
 // f_park without the trip through registers: gfx950's global_load_lds writes each lane's 16 bytes straight to
 // LDS (destination = wave-uniform base + 16 * lane: exactly the parked layout) and completes asynchronously under vmcnt, so the
 // NEXT select candidate's row travels while the current one is being compared.  Lanes past the row's end store zeros themselves.
-__device__ __forceinline__ void f_park_async(const FusedParams &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+__device__ __forceinline__ void f_park_async(const FRows &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
 {
     for (uint32_t c = 0; c < p.nch; c++) {
         const uint32_t off = c * 1024u + lane * 16u;
@@ -351,7 +361,7 @@ __device__ __forceinline__ void f_park_async(const FusedParams &p, const uint8_t
 // are read by ONE load instruction, and up to eight such instructions are in flight, so a whole neighbour list is one hop.
 // The bits are the canonical ones: the lanes a short row does not reach contribute +0.0 partials in the 64-lane order.
 template <class OP, int LPR>
-__device__ __forceinline__ float f_dist_small(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
+__device__ __forceinline__ float f_dist_small(const FRows &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
 {
     constexpr int R = 64 / LPR, PF = 8;
     const uint32_t g = lane / LPR, loff = (lane % LPR) * 16u;
@@ -389,7 +399,7 @@ template <int LPR> __device__ __forceinline__ constexpr uint32_t f_step_rows() {
 // FUSED_RB rows x FUSED_CG 1-KiB chunks are requested at once (one HBM latency per row batch at d <= 768 f32), then
 // consumed chunk by chunk in ascending order -- the canonical per-lane order.
 template <class OP, int LPR, int RB = FUSED_RB>
-__device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
+__device__ __forceinline__ float f_dist_batch(const FRows &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
     if constexpr (LPR < 64) return f_dist_small<OP, LPR>(p, qv, ids, n, lane);
     float mine = 0.0f;
@@ -478,7 +488,7 @@ __device__ __forceinline__ float f_dist_batch(const FusedParams &p, const uint8_
 // order and the scan stops at the first batch that contains a hit, like the reference's early `return false`
 // (the answer is the same; fewer rows are streamed for rejected candidates).  *n_eval += rows evaluated.
 template <class OP, int LPR>
-__device__ __forceinline__ bool f_any_le(const FusedParams &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
+__device__ __forceinline__ bool f_any_le(const FRows &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
                                          unsigned long long &n_eval)
 {
     constexpr uint32_t B = f_step_rows<LPR>();
@@ -508,7 +518,7 @@ enum { SQ_REQ = 0, SQ_NEXT = 1, SQ_DONE = 2, SQ_QOFF = 3, SQ_IOFF = 4, SQ_WORDS 
 
 // takes one batch of the request posted in slot s, if any is left, and evaluates it; false: nothing to take there
 template <class OP>
-__device__ __forceinline__ bool f_stream_serve(const FusedParams &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t s, uint32_t lane)
+__device__ __forceinline__ bool f_stream_serve(const FRows &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t s, uint32_t lane)
 {
     volatile uint32_t *q = (volatile uint32_t *)(lds + (size_t)s * slot_bytes + sq_off);
     const uint32_t req = __hip_atomic_load((const uint32_t *)&q[SQ_REQ], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -538,7 +548,7 @@ __device__ __forceinline__ bool f_stream_serve(const FusedParams &p, uint8_t *ld
 // Posts the rows ids[0..n) against the vector parked at qv and returns lane j's distance.  While the request is open the posting wave is
 // a stream wave itself: it takes batches of its own request first, then of its neighbours' -- a wave never idles next to unserved rows.
 template <class OP, int LPR>
-__device__ __forceinline__ float f_dist_posted(const FusedParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
+__device__ __forceinline__ float f_dist_posted(KParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
 {
     volatile uint32_t *q = cx.SQ;
     F_BAR();                                                        // the ids (written by any lane) are in LDS before the request is
@@ -552,7 +562,7 @@ __device__ __forceinline__ float f_dist_posted(const FusedParams &p, FusedCtx &c
     F_BAR();
     uint32_t probe = cx.my_slot;
     while (__hip_atomic_load((const uint32_t *)&q[SQ_DONE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n) {
-        if (f_stream_serve<OP>(p, cx.lds_base, cx.slot_bytes, cx.sq_off, cx.dout_off, probe, lane)) { probe = cx.my_slot; continue; }
+        if (f_stream_serve<OP>(cx.fr, cx.lds_base, cx.slot_bytes, cx.sq_off, cx.dout_off, probe, lane)) { probe = cx.my_slot; continue; }
         probe = probe + 1u < cx.nc ? probe + 1u : 0u;
         if (probe == cx.my_slot) __builtin_amdgcn_s_sleep(1);       // a full round without work: the rest of my rows is in other waves' registers
     }
@@ -564,14 +574,14 @@ __device__ __forceinline__ float f_dist_posted(const FusedParams &p, FusedCtx &c
 
 // query-vs-rows distances of one expansion / one check_element_closer step: by this wave itself, or posted to the stream waves
 template <class OP, int LPR, bool POSTED, int RB = FUSED_RB>
-__device__ __forceinline__ float f_dist(const FusedParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
+__device__ __forceinline__ float f_dist(KParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
     if constexpr (POSTED) return f_dist_posted<OP, LPR>(p, cx, qv, ids, n, lane);
-    else return f_dist_batch<OP, LPR, RB>(p, qv, ids, n, lane, tk);
+    else return f_dist_batch<OP, LPR, RB>(cx.fr, qv, ids, n, lane, tk);
 }
 
 template <class OP, int LPR, bool POSTED>
-__device__ __forceinline__ bool f_any_le_x(const FusedParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
+__device__ __forceinline__ bool f_any_le_x(KParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
                                            unsigned long long &n_eval)
 {
     constexpr uint32_t B = f_step_rows<LPR>();
@@ -586,7 +596,7 @@ __device__ __forceinline__ bool f_any_le_x(const FusedParams &p, FusedCtx &cx, c
 
 // a stream wave: serves the nc searches of its workgroup until every control wave has quit
 template <class OP>
-__device__ void f_stream_loop(const FusedParams &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t nc,
+__device__ void f_stream_loop(const FRows &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t nc,
                               volatile uint32_t *quit, uint32_t lane, uint32_t sw)
 {
     uint32_t s = sw % nc, idle = 0;

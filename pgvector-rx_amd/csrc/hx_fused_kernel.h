@@ -10,7 +10,7 @@
 // resumes (fresh == false keeps it; eps_visited == false: resume_scan_items' entry points are already in it), and every
 // visited element that does not end in W goes to the `discarded` min-heap, in the reference's order of pushes.
 template <class OP, int LPR, bool ITER = false, bool POSTED = false>
-__device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
+__device__ void f_search_layer(KParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
 {
     const uint32_t lane = cx.lane;
     // A greedy step (ef = 1) visits a few dozen ids: it uses the first 1 024 words of the table, so clearing costs 4 KB instead of 32-64 KB per
@@ -283,7 +283,7 @@ __device__ void f_search_layer(const FusedParams &p, FusedCtx &cx, uint32_t n_ep
 // redoing them inside the same kernel needs the heap code and its registers next to this one and was slower than the heap kernel alone.
 // Opt-in: HX_SORTED_ARRAY=1.
 template <class OP, int LPR, bool POSTED>
-__device__ void f_search_layer_sa(const FusedParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer)
+__device__ void f_search_layer_sa(KParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer)
 {
     constexpr uint32_t XF = 0x80000000u;
     const uint32_t lane = cx.lane;
@@ -429,7 +429,7 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
 // visited table / spill area / discarded heap in global memory).  MODE 0: query (get_scan_items), 1: insert (find_element_neighbors),
 // 2: iterative scan; LPR: lanes per row (64, or 8/32 for short rows); POSTED: rows are evaluated by the workgroup's stream waves (k_fused2).
 template <class OP, int MODE, int LPR, bool POSTED, bool SA = false>
-__device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *lds_base, const uint32_t slot, const uint32_t lane_in,
+__device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_base, const uint32_t slot, const uint32_t lane_in,
                                          const uint32_t slot_bytes = 0, const uint32_t sq_off = 0, const uint32_t dout_off = 0, const uint32_t nc = 1, const uint32_t my_slot = 0)
 {
     FusedCtx cx;
@@ -444,9 +444,9 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
     cx.RL = cx.RES + 64;
     cx.IDS = (uint32_t *)(cx.RL + lm0);
     cx.CTL = cx.IDS + 64;
-    p.dsc = (float *)(cx.CTL + 32);
-    cx.SQ = (volatile uint32_t *)(cx.CTL + 16); cx.DOUT = p.dsc; cx.lds_base = lds_base; cx.gen = 0;
-    cx.QV = (uint8_t *)(p.dsc + 64);                      // query parked in LDS (nch KiB)
+    cx.fr.rows = p.rows; cx.fr.pitch = p.pitch; cx.fr.nch = p.nch; cx.fr.dsc = (float *)(cx.CTL + 32);
+    cx.SQ = (volatile uint32_t *)(cx.CTL + 16); cx.DOUT = cx.fr.dsc; cx.lds_base = lds_base; cx.gen = 0;
+    cx.QV = (uint8_t *)(cx.fr.dsc + 64);                      // query parked in LDS (nch KiB)
     cx.DP = (lds_uint2 *)(cx.QV + p.nch * 1024u);          // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
     cx.WS = cx.DP + 64; cx.LV = (uint32_t *)(cx.WS + 160);   // working set of a flush (<= 2*64 + depth entries), per-level {first index, offset}
     cx.DS.A = cx.WS + 160 + 32; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
@@ -470,7 +470,7 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
         cx.status = FS_OK;
         const uint32_t qsel = p.t_qsel[t];
         const uint8_t *qsrc = (qsel & HX_QUERY_SLOT) ? p.queries + (size_t)(qsel & 0x7fffffffu) * p.pitch : p.rows + (size_t)qsel * p.pitch;
-        f_park(p, qsrc, lane, cx.QV);
+        f_park(cx.fr, qsrc, lane, cx.QV);
         const int new_level = MODE == 1 ? p.t_level[t] : -1;
         // MODE 1 outputs are addressed through strides so that one launch can fill either the SoA staging arrays or the AoS records
         // of a batch's exchange buffer (hx_batch.hip); os = output slot of this task
@@ -643,7 +643,7 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // e's own row and list (requested one iteration ago) have landed
                         F_BAR();
                         const uint32_t my_id = nx_id; const float my_d = nx_d;       // e's list slot of this lane
-                        if (i + 1u < wl) { const uint32_t en = cx.EP[i + 1u].y; f_park_async(p, p.rows + (size_t)en * p.pitch, lane, evb[(i + 1u) & 1u]); list_prefetch(en); }
+                        if (i + 1u < wl) { const uint32_t en = cx.EP[i + 1u].y; f_park_async(cx.fr, p.rows + (size_t)en * p.pitch, lane, evb[(i + 1u) & 1u]); list_prefetch(en); }
                         if (r > 0 && i > 0) {
                             bool known_hit = false;
                             if (my_id != 0xFFFFFFFFu && my_d <= fh_d(e)) for (uint32_t j = 0; j < r; j++) known_hit |= cx.RL[j].y == my_id;
@@ -661,7 +661,7 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no row may still be in flight towards the query's slot
                     F_BAR();
-                    f_park(p, qsrc, lane, cx.QV);                                    // the query again, for the next layer's search
+                    f_park(cx.fr, qsrc, lane, cx.QV);                                    // the query again, for the next layer's search
                     if (lane == 0) for (uint32_t j = 0; j < nd && r < lm; j++) cx.RL[r++] = cx.DL[j];   // mod.rs:300-305
                     r = __shfl(r, 0, 64);
                 }
@@ -682,20 +682,22 @@ __device__ __forceinline__ void f_worker(FusedParams &p, uint8_t *lds, uint8_t *
 
 template <class OP, int MODE, int LPR, bool SA = false>
 __global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : MODE == 1 ? FUSED_MINW_INS : SA ? FUSED_MINW_SA : FUSED_MINW))
-k_fused(const FusedParams p_in)
+k_fused(const FusedParams p_unused)
 {
-    FusedParams p = p_in;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    f_worker<OP, MODE, LPR, false, SA>(p, lds, lds, blockIdx.x, threadIdx.x);
+    KParams *kp = (KParams *)__builtin_amdgcn_kernarg_segment_ptr();      // the parameter block is the kernel's only argument: offset 0 of the kernarg segment
+    asm volatile("" : "+s"(kp));                                          // laundered (hx_fused_core.h: KParams)
+    f_worker<OP, MODE, LPR, false, SA>(*kp, lds, lds, blockIdx.x, threadIdx.x);
 }
 
 #ifdef HX_EXPERIMENTS
 // k_fused2: nc control waves (one search each, f_worker<POSTED>) + stream waves (f_stream_loop) per 1024-thread workgroup; see hx_fused_core.h
 template <class OP, int MODE>
 __global__ void __launch_bounds__(1024, 1)
-k_fused2(const FusedParams p_in, const uint32_t nc, const uint32_t slot_bytes)
+k_fused2(const FusedParams p_unused, const uint32_t nc, const uint32_t slot_bytes)
 {
-    FusedParams p = p_in;
+    KParams *kp = (KParams *)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(kp));
+    KParams &p = *kp;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     volatile uint32_t *quit = (volatile uint32_t *)(lds + (size_t)nc * slot_bytes);
@@ -708,7 +710,7 @@ k_fused2(const FusedParams p_in, const uint32_t nc, const uint32_t slot_bytes)
         f_worker<OP, MODE, 64, true>(p, lds + (size_t)wave * slot_bytes, lds, blockIdx.x * nc + wave, lane, slot_bytes, sq_off, dout_off, nc, wave);
         if (lane == 0) (void)__hip_atomic_fetch_add((uint32_t *)quit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-        FusedParams ps = p; ps.dsc = nullptr;
+        const FRows ps{p.rows, p.pitch, p.nch, nullptr};
         f_stream_loop<OP>(ps, lds, slot_bytes, sq_off, dout_off, nc, quit, lane, wave - nc);
     }
 }

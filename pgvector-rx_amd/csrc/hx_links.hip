@@ -247,7 +247,7 @@ k_pm_fill(const LinksParams p, float *pm, uint8_t *pm_valid)
 // SPEC == true: touches only the scratch arrays and answers "would this op change the list?" -- false only when it is certain
 // that the new row is the one left out and every survivor keeps its slot (then list, distances and matrix stay as they are).
 template <class OP, int LPR, bool SPEC, int SLOTS = LC_SLOTS>   // SLOTS: list capacity the kernel is built for (32: m <= 16, 64: m <= 32); also the index that stands for the new row
-__device__ bool lc_op(const FusedParams &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
+__device__ bool lc_op(const FRows &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
                       float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, uint8_t *QV,
                       uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist, unsigned long long *tk = nullptr,
                       const uint2 *wt = nullptr, const uint32_t wt_mask = 0)
@@ -429,7 +429,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x >= p.n_groups) return;
     const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
-    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u; fp.dsc = DSC;
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC};
     const uint32_t target = p.target[g], layer = p.layer[g];
     const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
     uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;
@@ -498,7 +498,7 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
     uint8_t *QV = (uint8_t *)(DSC + 64);
     if (blockIdx.x >= p.n_groups) return;
     const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
-    FusedParams fp; fp.rows = p.rows; fp.pitch = p.pitch; fp.nch = (p.pitch + 1023u) / 1024u; fp.dsc = DSC;
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC};
     const uint32_t target = p.target[g], layer = p.layer[g];
     const uint32_t lm = layer == 0 ? 2u * p.m : p.m;
     uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt;

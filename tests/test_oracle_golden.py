@@ -413,6 +413,20 @@ def _vacuum_gate_data(gate, rng):
     return rows, qs, exact
 
 
+def _bit_population_queries(gate, rows, nq):
+    """nq further random bit queries for a bit gate and their exact answers among the kept rows (ties with the k-th distance count)."""
+    rng = np.random.default_rng(2200)
+    dim, k, keep = gate["dim"], gate["k"], gate["keep"]
+    qbits = rng.integers(0, 2, (nq, dim)).astype(np.uint8)
+    bits = np.unpackbits(rows[:keep], axis=1, bitorder="big")[:, :dim]
+    d = (qbits[:, None, :] != bits[None, :, :]).sum(2)
+    exact = []
+    for q in range(nq):
+        kth = np.sort(d[q], kind="stable")[k - 1]
+        exact.append((np.nonzero(d[q] <= kth)[0] + 1).tolist())
+    return np.packbits(qbits, axis=1, bitorder="big"), exact
+
+
 def _gate_data(gate, rng, n):
     """Rows and queries with the distributions of the reference's recall tests (012:11, 020:62, 024:12, 028:11), encoded for the oracle."""
     tname, dim = gate["type"], gate["dim"]
@@ -476,9 +490,109 @@ def test_vacuum_recall_gate(gate):
     for g in gate["after_vacuum"]:
         r = _live_recall(idx, qs, exact, g["ef_search"], k, lambda t: True)
         assert r >= g["min_recall"] - gate.get("noise", 0.0), ("after", g, r)
+        if gate.get("population_queries"):      # the gate's stated threshold, no allowance, on a query sample large enough to measure the graph rather than the sample
+            q2, ex2 = _bit_population_queries(gate, rows, gate["population_queries"])
+            r2 = _live_recall(idx, q2, ex2, g["ef_search"], k, lambda t: True)
+            assert r2 >= g["min_recall"], ("after, population", g, r2)
     # nothing dead is returned any more, and no live element links to a deleted one
     assert all(t <= keep for q in qs for t, _, _ in idx.scan(q, ef_search=100))
     for e in range(n):
         if not idx.deleted(e):
             for layer in range(idx.level(e) + 1):
                 assert all(not idx.deleted(int(x)) for x in idx.neighbors(e, layer)[0])
+
+
+# ---- duplicates for every type, through CREATE INDEX and through aminsert (tests/t/015, 023, 027, 031) ----------------------------------
+def _dup_row(case):
+    if case["type"] == "bit":
+        return orc.pack_bits(case["row"])
+    v = np.asarray(case["row"], np.float32)
+    if case["type"] == "halfvec":
+        return v.astype(np.float16).view(np.uint16)
+    if case["type"] == "sparsevec":
+        return orc.sparse_from_dense(v)
+    return v
+
+
+@pytest.mark.parametrize("case", G["limits"]["duplicates_20_identical_rows_all_types"]["cases"], ids=lambda c: c["ref"].split("/")[-1].split(".")[0])
+@pytest.mark.parametrize("path", ["build", "aminsert"])
+def test_duplicates_all_types_both_paths(case, path):
+    """20 identical rows -> 2 elements of 10 heap TIDs -> a scan with ef_search = 1 returns exactly 10 rows: rows present at CREATE INDEX
+    (build.rs:482-512; 0xx:34-37) and rows inserted one by one into the truncated index (insert.rs:1136-1214; 0xx:39-46)."""
+    dt = TYPE[case["type"]]
+    row = _dup_row(case)
+    idx = orc.Index(dt, METRIC[case["metric"]], case["dim"], m=16, ef_construction=64)
+    rng = np.random.default_rng(23)
+    for tid in range(20):
+        lv = int(orc.levels_from_seed(20, 16, 23)[tid])
+        (idx.insert if path == "build" else idx.insert_on_disk)(row, lv, tid)
+    live = [i for i in range(idx.size) if not idx.merged(i)]
+    assert sorted(len(idx.tids(i)) for i in live) == [10, 10]
+    res = idx.scan(row, ef_search=1)
+    assert len(res) == G["limits"]["duplicates_20_identical_rows_all_types"]["expect_returned"]
+
+
+# ---- the stop rule of iterative scans (tests/t/043) ---------------------------------------------------------------------------------
+def _max_scan_tuples_data():
+    g = G["max_scan_tuples_gate"]
+    rng = np.random.default_rng(43)
+    rows = rng.random((g["rows"], g["dim"])).astype(np.float32)
+    return g, rows, orc.levels_from_seed(g["rows"], g["m"], 43)
+
+
+def test_max_scan_tuples_gate():
+    """tests/t/043_hnsw_iterative_scan.pl at its full size: with max_scan_tuples = 100000 all 10 rows with i % 10000 = 0 are found; with 30000 / 50000 /
+    70000 the average number found over 20 queries is within 2 of max_scan_tuples / 10000 (scan.rs:827-841: resuming stops once that many tuples were
+    returned, then `discarded` is drained one element at a time)."""
+    g, rows, levels = _max_scan_tuples_data()
+    idx = orc.Index(orc.F32, orc.L2SQ, g["dim"], m=g["m"], ef_construction=g["ef_construction"])
+    idx.build(rows, levels, batch=1, tids=np.arange(1, g["rows"] + 1))            # i = 1..n (generate_series)
+
+    def count(q, max_tuples):
+        got = [t for t, _, _ in idx.scan(q, ef_search=g["ef_search"], iterative=orc.ITER_RELAXED, max_scan_tuples=max_tuples) if t % g["filter_mod"] == 0]
+        return len(got[:g["limit"]])
+    assert count(rows[0], g["full"]["max_scan_tuples"]) == g["full"]["expect_count"]
+    for part in g["partial"]:
+        avg = sum(count(rows[i], part["max_scan_tuples"]) for i in range(part["queries"])) / part["queries"]
+        assert part["expect_avg"] - part["slack"] < avg < part["expect_avg"] + part["slack"], (part, avg)
+
+
+# ---- sparsevec: aminsert into an empty index + DELETE + VACUUM, three rounds (tests/t/038) ----------------------------------------------
+def sparse_038_rows(rng, n, dim, max_entries):
+    """Rows as 038:19-33 makes them: int(rand() * 100) draws of an index in [1, dim - 1] (duplicates dropped), values rand(); possibly none."""
+    out = []
+    for _ in range(n):
+        seen = {}
+        for _ in range(int(rng.random() * (max_entries + 1))):
+            ix = int(rng.random() * (dim - 1)) + 1
+            if ix not in seen:
+                seen[ix] = np.float32(rng.random())
+        ks = sorted(seen)
+        out.append((np.asarray([k - 1 for k in ks], np.int32), np.asarray([seen[k] for k in ks], np.float32)))     # text indices are 1-based
+    return out
+
+
+def test_sparsevec_vacuum_insert_rounds():
+    """tests/t/038_hnsw_sparsevec_vacuum_insert.pl: nothing errors, and what the reference leaves implicit: after every VACUUM no dead TID is
+    returned and no live element links to a deleted one; the inserts of the next round land in the vacuumed graph."""
+    g = G["sparsevec_vacuum_insert"]
+    rng = np.random.default_rng(38)
+    dim = g["dim"]
+    idx = orc.Index(orc.SPARSE, orc.L2SQ, dim, m=g["m"], ef_construction=g["ef_construction"])
+    levels = orc.levels_from_seed(g["rounds"] * g["inserts_per_round"], g["m"], 38)
+    serial, dead = 0, set()
+    for _ in range(g["rounds"]):
+        rows = sparse_038_rows(rng, g["inserts_per_round"], dim, g["max_entries"])
+        for idxs, vals in rows:
+            serial += 1
+            idx.insert_on_disk(orc.pack_sparse(dim, idxs, vals), int(levels[serial - 1]), serial)
+        kill = [i for i in range(1, serial + 1) if i % g["delete_mod"] == 0 and i not in dead]
+        idx.vacuum(np.asarray(kill, np.int64))
+        dead.update(kill)
+        q = orc.pack_sparse(dim, *rows[0])
+        got = [t for t, _, _ in idx.scan(q, ef_search=40)]
+        assert got and not (set(got) & dead)
+        for e in range(idx.size):
+            if not idx.deleted(e) and not idx.merged(e):
+                for layer in range(idx.level(e) + 1):
+                    assert all(not idx.deleted(int(x)) for x in idx.neighbors(e, layer)[0])
