@@ -133,13 +133,11 @@ int hx_engine::mirror_download(uint64_t n_elems, uint64_t n_blocks, uint32_t *l0
     return HX_OK;
 }
 
-// k_fused2 (pooled stream waves) and the sorted-array search are measured-slower / tie-inexact experiments: compiled only with
-// HX_CFLAGS=-DHX_EXPERIMENTS, selected by HX_FUSED2=1 / HX_SORTED_ARRAY=1
+// The sorted-array search is a tie-inexact experiment: compiled only with HX_CFLAGS=-DHX_EXPERIMENTS, selected by HX_SORTED_ARRAY=1.
+// (k_fused2, the pooled-stream-waves kernel of round 2 -- measured 0.29-0.38 of peak against 0.50 -- was removed in round 3; it is in the history.)
 #ifdef HX_EXPERIMENTS
-static int fused2_env_on() { static const int v = getenv("HX_FUSED2") ? atoi(getenv("HX_FUSED2")) : 0; return v; }
 static int sa_env_on() { return getenv("HX_SORTED_ARRAY") ? atoi(getenv("HX_SORTED_ARRAY")) : 0; }
 #else
-static int fused2_env_on() { return 0; }
 static int sa_env_on() { return 0; }
 #endif
 
@@ -183,7 +181,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     if (mode == 2 && (!it || !it->emask || !it->out_tix)) return fail(HX_E_ARG, "iterative scan arguments missing");
     if (dev && mode != 1) return fail(HX_E_ARG, "device-resident results are an insert-mode feature");
     HX_HIP(this, hipSetDevice(device));
-    // LDS: C[ccap] W[ef+2] EP[ef+2] RES[64] RL[2m] DL[ef+2] (8 B each) + IDS[64] + CTL[16] (4 B each)
+    // LDS (carved in hx_fused_kernel.h f_worker): IDS[64] CTL[32] dsc[64] (4 B each) | RES[64] RL[64] (8 B each) | query (nch KiB) | W[ef+2] EP[ef+2] C[clds] (8 B each)
     // candidate heap: up to FUSED_CCAP entries, the first `clds` in LDS and the tail in a per-workgroup spill area
     // (the largest heap seen on 1M x 768 builds was 1552 entries at ef = 200); beyond FUSED_CCAP a task reports
     // FS_OVERFLOW and is re-run by the lock-step path
@@ -198,11 +196,11 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     // HX_SORTED_ARRAY=1 (opt-in experiment, hx_fused_kernel.h: f_search_layer_sa): first launches of queries search on one sorted array; a query that
     // meets a tie reports FS_OVERFLOW and its retry launch (roomy > 1) uses the heap kernel, which is exact for any input
     const int sa_env = sa_env_on();
-    const bool sa = sa_env && roomy == 1 && mode == 0 && dtype != HX_BIT && ef > 1 && ef <= 256 && !fused2_env_on();
+    const bool sa = sa_env && roomy == 1 && mode == 0 && dtype != HX_BIT && ef > 1 && ef <= 256;
     if (sa) clds = 0;                                            // no candidate heap
     if (mode == 1) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
     if (dev && dev->d_wtab) clds = std::max<uint32_t>(clds, dev->wt_size);                     // so does the W table
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 2 * mr.m) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 64) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };   // f_worker's carve
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     const size_t waves_cap = 4u * (size_t)(mode == 2 ? FUSED_MINW_ITER : mode == 1 ? FUSED_MINW_INS : FUSED_MINW);   // register-file limit: launch_bounds waves per SIMD x 4 SIMDs
@@ -210,16 +208,6 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     { const char *pv = getenv(mode == 0 ? "HX_QUERY_PER_CU" : "HX_INSERT_PER_CU"); if (mode != 2 && pv && atoi(pv) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(pv)); }   // tuning knob
     per_cu = std::min<uint32_t>(per_cu, FUSED_SLOTS_PER_CU);
     uint32_t grid = std::min<uint32_t>(ntasks, 256u * per_cu);
-    // k_fused2 (rows wider than 512 B, queries and inserts): one 1024-thread workgroup per CU, nc control waves + (16 - nc) stream waves
-    const int fused2_env = fused2_env_on();   // experimental pooled-stream kernel: opt-in (measured slower than one wave per search so far)
-    const uint32_t slot_bytes = (uint32_t)((lds + 15) & ~(size_t)15);
-    uint32_t nc2 = 0;
-    if (fused2_env && mode != 2 && pitch > 512 && ntasks >= 64) {
-        nc2 = (uint32_t)std::min<size_t>(15, (160 * 1024 - 256) / slot_bytes);
-        { const char *cv = getenv("HX_FUSED2_NC"); if (cv && atoi(cv) > 0) nc2 = std::min<uint32_t>(nc2, (uint32_t)atoi(cv)); }   // tuning knob
-        if (nc2 < 4) nc2 = 0;                                      // very wide rows with a large ef: too few searches per workgroup to feed stream waves
-        else grid = std::min<uint32_t>((ntasks + nc2 - 1) / nc2, 256u);
-    }
     // >= 2x the ids a search touches at its usual ~ef expansions; twice that on indexes of >= 4M rows, where some searches reach further.
     // Measured on 1M x 768: a table twice as large costs 3-6 % of the scan rate (cache footprint), one half as large overflows and retries.
     const uint64_t vis_need = ((uint64_t)ef * 2 * mr.m * 2 + 1024) * (n_rows >= 4000000ull ? 2 : 1);
@@ -334,11 +322,6 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     if (timing) HX_HIP(this, hipEventRecord(io.ev0, stream));
     hipError_t ls = hipSuccess;
     fused_stream = stream;
-#ifdef HX_EXPERIMENTS
-    if (nc2) ls = dtype == HX_F32 ? hx_launch_fused2_f32(this, metric, p, grid, nc2, slot_bytes, mode)
-               : dtype == HX_F16 ? hx_launch_fused2_f16(this, metric, p, grid, nc2, slot_bytes, mode) : hx_launch_fused2_bit(this, metric, p, grid, nc2, slot_bytes, mode);
-    else
-#endif
     ls = dtype == HX_F32 ? hx_launch_fused_f32(this, metric, p, grid, lds, mode)
             : dtype == HX_F16 ? hx_launch_fused_f16(this, metric, p, grid, lds, mode) : hx_launch_fused_bit(this, metric, p, grid, lds, mode);
     HX_HIP(this, ls);

@@ -6,11 +6,3 @@ hipError_t hx_launch_fused_bit(hx_engine *e, int metric, const FusedParams &p, u
     if (metric == HX_HAMMING) return launch_fused_mode<OpHamming>(e, p, grid, lds, mode);
     return launch_fused_mode<OpJaccard>(e, p, grid, lds, mode);
 }
-
-#ifdef HX_EXPERIMENTS
-hipError_t hx_launch_fused2_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode)
-{
-    if (metric == HX_HAMMING) return launch_fused2_mode<OpHamming>(e, p, grid, nc, slot_bytes, mode);
-    return launch_fused2_mode<OpJaccard>(e, p, grid, nc, slot_bytes, mode);
-}
-#endif

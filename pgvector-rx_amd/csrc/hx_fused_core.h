@@ -67,14 +67,14 @@ struct FusedParams {
 // pointer the compiler cannot see through (k_fused launders it): a field is then s_load-ed where it is used -- hoisted out of a loop only when
 // the loop always reads it -- instead of all ~60 dwords being loaded at kernel entry and held live (or spilled) to the end.
 typedef const __attribute__((address_space(4))) FusedParams KParams;
+// A fresh, opaque copy of the parameter pointer: loads through it cannot be merged with (or hoisted above) loads through an older copy, so what a
+// phase derives from the parameters is computed where the phase starts and is dead when it ends, instead of living from kernel entry to exit.
+__device__ __forceinline__ KParams &f_params_here(KParams &p) { KParams *q = &p; asm volatile("" : "+s"(q)); return *q; }
 
 // one translation unit per element type holds the k_fused instantiations (hx_fused_f32.hip / _f16.hip / _bit.hip)
 hipError_t hx_launch_fused_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_f16(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
-hipError_t hx_launch_fused2_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
-hipError_t hx_launch_fused2_f16(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
-hipError_t hx_launch_fused2_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode);
 
 // what the query-vs-rows helpers below need: the row store and 64 floats of LDS scratch for the short-row path.  Kept apart from FusedParams
 // so that the kernel's parameters stay an immutable kernel argument (fields are s_load-ed from the kernarg segment where they are used instead of
@@ -149,8 +149,8 @@ template <bool NEAREST> struct FHeap {
 //     same path is again one ballot, and all the moves are one store.
 // The resulting array is the one the serial algorithm leaves, element for element (ties included).
 #define F_WSYNC() asm volatile("" ::: "memory")     /* LDS ops of one wave execute in order; only the compiler must not reorder */
-/* A search is driven by ONE wavefront, also when its workgroup has others (k_fused2): what the traversal code needs between its steps is
-   ordering inside that wave -- its earlier LDS and memory operations issued before its later ones -- never a workgroup barrier. */
+/* A search is driven by ONE wavefront: what the traversal code needs between its steps is ordering inside that wave -- its earlier LDS and
+   memory operations issued before its later ones -- never a workgroup barrier. */
 #define F_BAR() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
 // heap storage for PHeap: plain LDS, or an LDS head + a tail in this workgroup's global area (the `discarded` heap of an
 // iterative scan holds every visited element that is not a result: tens of thousands of entries).  The global part is read
@@ -312,9 +312,6 @@ struct FusedCtx {
     uint32_t *vis; uint32_t lane; uint32_t status;
     GStore DS; lds_uint2 *DP, *WS; uint32_t *LV; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
-    // k_fused2: row batches are posted to the workgroup's streaming waves
-    volatile uint32_t *SQ; float *DOUT; uint8_t *lds_base; uint32_t gen;
-    uint32_t slot_bytes, sq_off, dout_off, nc, my_slot;
     uint32_t tph[14];  // [13] select phase; diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes
 };
 
@@ -502,111 +499,15 @@ __device__ __forceinline__ bool f_any_le(const FRows &p, const uint8_t *qv, cons
 }
 
 
-// =================================================================================================
-// Pooled row streaming (k_fused2).  One wave per search keeps the registers that hold rows in flight idle while it pops, looks
-// lists and visited buckets up and replays its heaps -- half of its time on the 1M x 768 workload -- and the register file is full
-// at 16 such waves per CU, so the idle share cannot be bought back with more waves.  In k_fused2 a workgroup has NC CONTROL waves
-// (one search each: heaps, lists, visited set, select -- no row ever enters their registers) and NS STREAM waves that do nothing
-// but evaluate row batches for whichever search has one posted: a control wave publishes {query parked in LDS, ids in LDS, n} in
-// its StreamQ, the stream waves carve the request into batches of FUSED_SRB rows with an LDS compare-and-swap, write the distances
-// to the search's LDS and count them done.  Same rows, same canonical summation order, same bits; only who loads them changed.
-// =================================================================================================
-#ifndef FUSED_SRB
-#define FUSED_SRB 8            /* rows in flight per stream wave (x FUSED_CG chunks: 96 VGPRs of row data) */
-#endif
-enum { SQ_REQ = 0, SQ_NEXT = 1, SQ_DONE = 2, SQ_QOFF = 3, SQ_IOFF = 4, SQ_WORDS = 8 };   // req / next: generation << 8 | count
-
-// takes one batch of the request posted in slot s, if any is left, and evaluates it; false: nothing to take there
-template <class OP>
-__device__ __forceinline__ bool f_stream_serve(const FRows &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t s, uint32_t lane)
+// query-vs-rows distances of one expansion / one check_element_closer step
+template <class OP, int LPR, int RB = FUSED_RB>
+__device__ __forceinline__ float f_dist(FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
-    volatile uint32_t *q = (volatile uint32_t *)(lds + (size_t)s * slot_bytes + sq_off);
-    const uint32_t req = __hip_atomic_load((const uint32_t *)&q[SQ_REQ], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t n = req & 0xFFu;
-    if (n == 0u) return false;
-    uint32_t got = 0xFFFFFFFFu;
-    if (lane == 0) {
-        const uint32_t v = q[SQ_NEXT];
-        if ((v >> 8) == (req >> 8) && (v & 0xFFu) < n) {
-            uint32_t expect = v;
-            if (__hip_atomic_compare_exchange_strong((uint32_t *)&q[SQ_NEXT], &expect, v + (uint32_t)FUSED_SRB, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) got = v & 0xFFu;
-        }
-    }
-    got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-    if (got == 0xFFFFFFFFu) return false;
-    const uint32_t cnt = n - got < (uint32_t)FUSED_SRB ? n - got : (uint32_t)FUSED_SRB;
-    const uint8_t *qv = lds + q[SQ_QOFF];
-    const uint32_t *ids = (const uint32_t *)(lds + q[SQ_IOFF]) + got;
-    volatile float *dout = (volatile float *)(lds + (size_t)s * slot_bytes + dout_off) + got;
-    const float mine = f_dist_batch<OP, 64, FUSED_SRB>(p, qv, ids, cnt, lane);
-    if (lane < cnt) dout[lane] = mine;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) (void)__hip_atomic_fetch_add((uint32_t *)&q[SQ_DONE], cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return true;
+    return f_dist_batch<OP, LPR, RB>(cx.fr, qv, ids, n, lane, tk);
 }
 
-// Posts the rows ids[0..n) against the vector parked at qv and returns lane j's distance.  While the request is open the posting wave is
-// a stream wave itself: it takes batches of its own request first, then of its neighbours' -- a wave never idles next to unserved rows.
 template <class OP, int LPR>
-__device__ __forceinline__ float f_dist_posted(KParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
+__device__ __forceinline__ bool f_any_le_x(FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr, unsigned long long &n_eval)
 {
-    volatile uint32_t *q = cx.SQ;
-    F_BAR();                                                        // the ids (written by any lane) are in LDS before the request is
-    cx.gen = (cx.gen + 1u) & 0xFFFFFFu;
-    if (lane == 0) {
-        q[SQ_DONE] = 0u; q[SQ_QOFF] = (uint32_t)(qv - cx.lds_base); q[SQ_IOFF] = (uint32_t)((const uint8_t *)ids - cx.lds_base);
-        q[SQ_NEXT] = cx.gen << 8;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        q[SQ_REQ] = (cx.gen << 8) | n;
-    }
-    F_BAR();
-    uint32_t probe = cx.my_slot;
-    while (__hip_atomic_load((const uint32_t *)&q[SQ_DONE], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n) {
-        if (f_stream_serve<OP>(cx.fr, cx.lds_base, cx.slot_bytes, cx.sq_off, cx.dout_off, probe, lane)) { probe = cx.my_slot; continue; }
-        probe = probe + 1u < cx.nc ? probe + 1u : 0u;
-        if (probe == cx.my_slot) __builtin_amdgcn_s_sleep(1);       // a full round without work: the rest of my rows is in other waves' registers
-    }
-    const float mine = lane < n ? ((volatile float *)cx.DOUT)[lane] : 0.0f;
-    if (lane == 0) q[SQ_REQ] = 0u;                                  // retired: nothing left to hand out
-    F_BAR();
-    return mine;
-}
-
-// query-vs-rows distances of one expansion / one check_element_closer step: by this wave itself, or posted to the stream waves
-template <class OP, int LPR, bool POSTED, int RB = FUSED_RB>
-__device__ __forceinline__ float f_dist(KParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
-{
-    if constexpr (POSTED) return f_dist_posted<OP, LPR>(p, cx, qv, ids, n, lane);
-    else return f_dist_batch<OP, LPR, RB>(cx.fr, qv, ids, n, lane, tk);
-}
-
-template <class OP, int LPR, bool POSTED>
-__device__ __forceinline__ bool f_any_le_x(KParams &p, FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
-                                           unsigned long long &n_eval)
-{
-    constexpr uint32_t B = f_step_rows<LPR>();
-    for (uint32_t j0 = 0; j0 < n; j0 += B) {
-        const uint32_t nb = n - j0 < B ? n - j0 : B;
-        const float d = f_dist<OP, LPR, POSTED>(p, cx, qv, ids + j0, nb, lane);
-        n_eval += nb;
-        if (__ballot(lane < nb && d <= thr) != 0ull) return true;
-    }
-    return false;
-}
-
-// a stream wave: serves the nc searches of its workgroup until every control wave has quit
-template <class OP>
-__device__ void f_stream_loop(const FRows &p, uint8_t *lds, uint32_t slot_bytes, uint32_t sq_off, uint32_t dout_off, uint32_t nc,
-                              volatile uint32_t *quit, uint32_t lane, uint32_t sw)
-{
-    uint32_t s = sw % nc, idle = 0;
-    for (;;) {
-        if (f_stream_serve<OP>(p, lds, slot_bytes, sq_off, dout_off, s, lane)) { idle = 0; continue; }   // stay on a slot while it has batches
-        s = s + 1u < nc ? s + 1u : 0u;
-        if (++idle >= nc) {
-            idle = 0;
-            if (__hip_atomic_load((const uint32_t *)quit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= nc) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
+    return f_any_le<OP, LPR>(cx.fr, qv, ids, n, lane, thr, n_eval);
 }

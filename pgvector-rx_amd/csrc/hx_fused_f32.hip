@@ -9,12 +9,3 @@ hipError_t hx_launch_fused_f32(hx_engine *e, int metric, const FusedParams &p, u
     default: return launch_fused_mode<OpF32<K_L1>>(e, p, grid, lds, mode);
     }
 }
-
-#ifdef HX_EXPERIMENTS
-hipError_t hx_launch_fused2_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode)
-{
-    if (metric == HX_L2SQ) return launch_fused2_mode<OpF32<K_L2>>(e, p, grid, nc, slot_bytes, mode);
-    if (metric == HX_NEG_IP) return launch_fused2_mode<OpF32<K_IP>>(e, p, grid, nc, slot_bytes, mode);
-    return launch_fused2_mode<OpF32<K_L1>>(e, p, grid, nc, slot_bytes, mode);
-}
-#endif

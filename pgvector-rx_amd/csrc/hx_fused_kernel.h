@@ -9,9 +9,10 @@
 // ITER: search_layer_disk WITH the iterative scan's state (scan.rs:302-448): the visited set is the caller's and survives
 // resumes (fresh == false keeps it; eps_visited == false: resume_scan_items' entry points are already in it), and every
 // visited element that does not end in W goes to the `discarded` min-heap, in the reference's order of pushes.
-template <class OP, int LPR, bool ITER = false, bool POSTED = false>
-__device__ void f_search_layer(KParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
+template <class OP, int LPR, bool ITER = false>
+__device__ __forceinline__ void f_search_layer(KParams &p_in, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
 {
+    KParams &p = f_params_here(p_in);
     const uint32_t lane = cx.lane;
     // A greedy step (ef = 1) visits a few dozen ids: it uses the first 1 024 words of the table, so clearing costs 4 KB instead of 32-64 KB per
     // layer of the descent (the clears were 4 % of a query's memory traffic).  Any table size gives the same visited SET; one that fills up reports
@@ -194,9 +195,9 @@ __device__ void f_search_layer(KParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t
             if (vcount * 4u > (uint32_t)vis_words * 3u) { cx.status = FS_OVERFLOW; break; }   // table too full: re-run in the lock-step path
             if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
-            if constexpr (POSTED || FUSED_BAR_BEFORE_ROWS) F_BAR(); else F_WSYNC();   // the ids are read back by this wave (LDS is in order); no wait for the visited-set CAS still in flight: it is settled after the row loads
+            if constexpr (FUSED_BAR_BEFORE_ROWS) F_BAR(); else F_WSYNC();   // the ids are read back by this wave (LDS is in order); no wait for the visited-set CAS still in flight: it is settled after the row loads
             F_TICK(3);
-            const float mine = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
+            const float mine = f_dist<OP, LPR>(cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
             F_TICK(4);
             vis_settle(cx.vis, bmask, e, vslot, vold);                               // the CAS results came back with the rows
             if (lane < cnt) cx.RES[lane] = fh_pack(mine, cx.IDS[lane]);
@@ -282,7 +283,7 @@ __device__ void f_search_layer(KParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t
 // ~1 700 f32 distances coincide more often than one would think -- and their retry launch is one search latency long (3.9 ms) however few they are;
 // redoing them inside the same kernel needs the heap code and its registers next to this one and was slower than the heap kernel alone.
 // Opt-in: HX_SORTED_ARRAY=1.
-template <class OP, int LPR, bool POSTED>
+template <class OP, int LPR>
 __device__ void f_search_layer_sa(KParams &p, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer)
 {
     constexpr uint32_t XF = 0x80000000u;
@@ -346,9 +347,9 @@ __device__ void f_search_layer_sa(KParams &p, FusedCtx &cx, uint32_t n_ep, uint3
             if (vcount * 4u > (uint32_t)vis_words * 3u) { cx.status = FS_OVERFLOW; break; }
             if (cnt == 0) { vis_settle(cx.vis, bmask, e, vslot, vold); continue; }
             if (unvis) cx.IDS[__popcll(mask & ((1ull << lane) - 1ull))] = e;
-            if constexpr (POSTED || FUSED_BAR_BEFORE_ROWS) F_BAR(); else F_WSYNC();   // the ids are read back by this wave (LDS is in order); no wait for the visited-set CAS still in flight: it is settled after the row loads
+            if constexpr (FUSED_BAR_BEFORE_ROWS) F_BAR(); else F_WSYNC();   // the ids are read back by this wave (LDS is in order); no wait for the visited-set CAS still in flight: it is settled after the row loads
             F_TICK(3);
-            const float mine = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
+            const float mine = f_dist<OP, LPR>(cx, cx.QV, cx.IDS, cnt, lane, tm ? cx.tph : nullptr);
             F_TICK(4);
             vis_settle(cx.vis, bmask, e, vslot, vold);
             cx.nd0 += cnt;
@@ -411,7 +412,7 @@ __device__ void f_search_layer_sa(KParams &p, FusedCtx &cx, uint32_t n_ep, uint3
 
 // stable sort of the W heap's internal array into EP: ascending (build, mod.rs:248-254) or descending (scan.rs:441-446);
 // rank sort: ties keep their order in W's array, exactly what a stable sort of that array does
-__device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
+__device__ __forceinline__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
 {
     for (uint32_t i = cx.lane; i < n; i += 64) {
         const uint2 me = cx.W[i]; const float d = fh_d(me);
@@ -427,27 +428,27 @@ __device__ void f_sort_results(FusedCtx &cx, uint32_t n, bool desc)
 
 // One search after the other, from the task counter, driven by ONE wavefront whose state lives in the LDS slot `lds` (`slot` selects its
 // visited table / spill area / discarded heap in global memory).  MODE 0: query (get_scan_items), 1: insert (find_element_neighbors),
-// 2: iterative scan; LPR: lanes per row (64, or 8/32 for short rows); POSTED: rows are evaluated by the workgroup's stream waves (k_fused2).
-template <class OP, int MODE, int LPR, bool POSTED, bool SA = false>
-__device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_base, const uint32_t slot, const uint32_t lane_in,
-                                         const uint32_t slot_bytes = 0, const uint32_t sq_off = 0, const uint32_t dout_off = 0, const uint32_t nc = 1, const uint32_t my_slot = 0)
+// 2: iterative scan; LPR: lanes per row (64, or 8/32 for short rows).
+template <class OP, int MODE, int LPR, bool SA = false>
+__device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint32_t slot, const uint32_t lane_in)
 {
     FusedCtx cx;
-    cx.slot_bytes = slot_bytes; cx.sq_off = sq_off; cx.dout_off = dout_off; cx.nc = nc; cx.my_slot = my_slot;
+    KParams &p = f_params_here(p_in);
     const uint32_t lm0 = 2u * p.m;
-    // LDS carve: C[ccap] | W[ef+2] | EP[ef+2] | RES[64] | RL[2m] | IDS[64] CTL[32] | dsc[64] | QV[nch KiB].  The select phase runs
-    // after the layer's search is over, so its scratch (the candidate under test EV and the discarded list DL) reuses C.
-    cx.C = (uint2 *)lds;
-    cx.W = cx.C + p.clds;
-    cx.EP = cx.W + (p.ef + 2);
-    cx.RES = cx.EP + (p.ef + 2);
-    cx.RL = cx.RES + 64;
-    cx.IDS = (uint32_t *)(cx.RL + lm0);
+    // LDS carve, fixed-size regions first so that their addresses are compile-time constants (no scalar register holds them):
+    //   IDS[64] u32 | CTL[32] u32 | dsc[64] f32 | RES[64] | RL[64] | QV[nch KiB] | W[ef+2] | EP[ef+2] | C[clds] | MODE 2: DP[64] WS[160] LV[32] DS[disc_lds]
+    // (8-byte entries unless noted; hx_fused.inc.h sizes the allocation).  The select phase runs after the layer's search is over, so its scratch
+    // (the candidate under test EV and the discarded list DL) reuses C.
+    cx.IDS = (uint32_t *)lds;
     cx.CTL = cx.IDS + 64;
-    cx.fr.rows = p.rows; cx.fr.pitch = p.pitch; cx.fr.nch = p.nch; cx.fr.dsc = (float *)(cx.CTL + 32);
-    cx.SQ = (volatile uint32_t *)(cx.CTL + 16); cx.DOUT = cx.fr.dsc; cx.lds_base = lds_base; cx.gen = 0;
-    cx.QV = (uint8_t *)(cx.fr.dsc + 64);                      // query parked in LDS (nch KiB)
-    cx.DP = (lds_uint2 *)(cx.QV + p.nch * 1024u);          // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
+    cx.fr.dsc = (float *)(cx.CTL + 32);
+    cx.RES = (uint2 *)(cx.fr.dsc + 64);
+    cx.RL = cx.RES + 64;
+    cx.QV = (uint8_t *)(cx.RL + 64);                      // query parked in LDS (nch KiB)
+    cx.W = (uint2 *)(cx.QV + p.nch * 1024u);
+    cx.EP = cx.W + (p.ef + 2);
+    cx.C = cx.EP + (p.ef + 2);
+    cx.DP = (lds_uint2 *)(cx.C + p.clds);                 // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
     cx.WS = cx.DP + 64; cx.LV = (uint32_t *)(cx.WS + 160);   // working set of a flush (<= 2*64 + depth entries), per-level {first index, offset}
     cx.DS.A = cx.WS + 160 + 32; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
     cx.DS.G = MODE == 2 ? p.disc + (size_t)slot * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
@@ -462,6 +463,8 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
     const uint32_t lane = cx.lane;
 
     for (;;) {
+        KParams &p = f_params_here(p_in);                  // per task: what the task derives from the parameters does not outlive it
+        cx.fr.rows = p.rows; cx.fr.pitch = p.pitch; cx.fr.nch = p.nch;
         if (lane == 0) cx.CTL[5] = atomicAdd(p.next_task, 1u);
         F_BAR();
         const uint32_t t = cx.CTL[5];
@@ -480,7 +483,7 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
         // d(q, entry point): mod.rs:371-377 / scan.rs:475
         if (lane == 0) cx.IDS[0] = p.entry;
         F_BAR();
-        const float d0 = f_dist<OP, LPR, POSTED>(p, cx, cx.QV, cx.IDS, 1, lane);
+        const float d0 = f_dist<OP, LPR>(cx, cx.QV, cx.IDS, 1, lane);
         cx.nd0 += 1;
         if (lane == 0) cx.EP[0] = fh_pack(d0, p.entry);
         F_BAR();
@@ -491,13 +494,13 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
 #ifdef HX_EXPERIMENTS
             if constexpr (SA) {
-                f_search_layer_sa<OP, LPR, POSTED>(p, cx, n_ep, 1u, lc);
+                f_search_layer_sa<OP, LPR>(p, cx, n_ep, 1u, lc);
                 if (cx.CTL[1] > 0) { const uint2 best = cx.W[0]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); n_ep = 1; }
                 else if (MODE != 1) { n_ep = 0; break; }
                 continue;
             }
 #endif
-            f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, 1u, lc, MODE != 1);
+            f_search_layer<OP, LPR, false>(p, cx, n_ep, 1u, lc, MODE != 1);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
                 f_sort_results(cx, wl, MODE != 1);
@@ -512,9 +515,12 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
             cx.dlen = 0; cx.vcount = 0;
             const size_t obase = (size_t)t * p.limit;
             if (cx.status == FS_OK && n_ep > 0) {
-                f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, true, true);           // scan.rs:515-528
-                bool single = false;
+                // ONE call site for the layer-0 search with the scan's state (the first search, scan.rs:515-528, and every resume, scan.rs:553-575): the
+                // function is inlined once -- called from two places it stayed an out-of-line function, and its call frame was the kernel's scratch
+                bool first = true, single = false;
                 for (;;) {
+                    if (!single) f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, first, first);
+                    first = false;
                     if (cx.status != FS_OK) break;
                     const uint32_t wl = single ? 1u : cx.CTL[1];
                     if (!single) f_sort_results(cx, wl, true);                                   // EP[0..wl): nearest LAST
@@ -555,7 +561,6 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
                         F_BAR(); if (lane == 0) cx.EP[n_ep] = x; F_BAR();
                         n_ep++;
                     }
-                    f_search_layer<OP, LPR, true>(p, cx, n_ep, p.ef, 0, true, false, false);
                 }
             }
             if (lane == 0) { p.out_cnt[t] = outc; p.status[t] = cx.status; }
@@ -564,7 +569,7 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
             if (cx.status == FS_OK && n_ep > 0) {
 #ifdef HX_EXPERIMENTS
                 if constexpr (SA) {
-                    f_search_layer_sa<OP, LPR, POSTED>(p, cx, n_ep, p.ef, 0);                        // scan.rs:515-528; W comes out ascending
+                    f_search_layer_sa<OP, LPR>(p, cx, n_ep, p.ef, 0);                        // scan.rs:515-528; W comes out ascending
                     const uint32_t wl = cx.CTL[1];
                     cnt = cx.status != FS_OK ? 0u : wl < p.k ? wl : p.k;
                     for (uint32_t i = lane; i < cnt; i += 64) {
@@ -574,7 +579,7 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
                 } else
 #endif
                 {
-                f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
+                f_search_layer<OP, LPR, false>(p, cx, n_ep, p.ef, 0, true);                  // scan.rs:515-528
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, true);                                        // nearest LAST
                 cnt = wl < p.k ? wl : p.k;
@@ -589,10 +594,12 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
             const int start = new_level < p.entry_level ? new_level : p.entry_level;
             const size_t obase = (size_t)os * p.o_cst;
             for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
+            KParams &p_task = p;
             for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
-                const uint32_t lm = lc == 0 ? lm0 : p.m;
-                f_search_layer<OP, LPR, false, POSTED>(p, cx, n_ep, p.ef, lc, false);                // mod.rs:407-416
+                f_search_layer<OP, LPR, false>(p_task, cx, n_ep, p_task.ef, lc, false);      // mod.rs:407-416
                 if (cx.status != FS_OK) break;
+                KParams &p = f_params_here(p_task);            // the select phase derives its own view of the parameters (dead again when the layer is done)
+                const uint32_t lm = lc == 0 ? lm0 : p.m;
                 const uint32_t wl = cx.CTL[1];
                 f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
                 n_ep = wl;
@@ -652,7 +659,7 @@ __device__ __forceinline__ void f_worker(KParams &p, uint8_t *lds, uint8_t *lds_
                         if (r > 0 && closer) {
                             if (lane < r) cx.IDS[lane] = cx.RL[lane].y;
                             F_BAR();
-                            closer = !f_any_le_x<OP, LPR, POSTED>(p, cx, evb[i & 1u], cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
+                            closer = !f_any_le_x<OP, LPR>(cx, evb[i & 1u], cx.IDS, r, lane, fh_d(e), cx.nd1);   // mod.rs:324-336
                             F_BAR();
                         }
                         if (lane == 0) { if (closer) cx.RL[r] = e; else cx.DL[nd] = e; }
@@ -687,35 +694,9 @@ k_fused(const FusedParams p_unused)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     KParams *kp = (KParams *)__builtin_amdgcn_kernarg_segment_ptr();      // the parameter block is the kernel's only argument: offset 0 of the kernarg segment
     asm volatile("" : "+s"(kp));                                          // laundered (hx_fused_core.h: KParams)
-    f_worker<OP, MODE, LPR, false, SA>(*kp, lds, lds, blockIdx.x, threadIdx.x);
+    f_worker<OP, MODE, LPR, SA>(*kp, lds, blockIdx.x, threadIdx.x);
 }
 
-#ifdef HX_EXPERIMENTS
-// k_fused2: nc control waves (one search each, f_worker<POSTED>) + stream waves (f_stream_loop) per 1024-thread workgroup; see hx_fused_core.h
-template <class OP, int MODE>
-__global__ void __launch_bounds__(1024, 1)
-k_fused2(const FusedParams p_unused, const uint32_t nc, const uint32_t slot_bytes)
-{
-    KParams *kp = (KParams *)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(kp));
-    KParams &p = *kp;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    volatile uint32_t *quit = (volatile uint32_t *)(lds + (size_t)nc * slot_bytes);
-    // offsets of a slot's StreamQ and distance outputs (the carve of f_worker)
-    const uint32_t ids_off = (p.clds + 2u * (p.ef + 2u) + 64u + 2u * p.m) * 8u, sq_off = ids_off + (64u + 16u) * 4u, dout_off = ids_off + (64u + 32u) * 4u;
-    if (threadIdx.x == 0) *quit = 0u;
-    if (wave < nc && lane < SQ_WORDS) *(volatile uint32_t *)(lds + (size_t)wave * slot_bytes + sq_off + lane * 4u) = 0u;
-    __syncthreads();                                               // the only workgroup barrier: the queues exist before anybody polls them
-    if (wave < nc) {
-        f_worker<OP, MODE, 64, true>(p, lds + (size_t)wave * slot_bytes, lds, blockIdx.x * nc + wave, lane, slot_bytes, sq_off, dout_off, nc, wave);
-        if (lane == 0) (void)__hip_atomic_fetch_add((uint32_t *)quit, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        const FRows ps{p.rows, p.pitch, p.nch, nullptr};
-        f_stream_loop<OP>(ps, lds, slot_bytes, sq_off, dout_off, nc, quit, lane, wave - nc);
-    }
-}
-
-#endif  // HX_EXPERIMENTS
 
 template <class OP, int MODE, int LPR, bool SA = false>
 static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds)
@@ -735,26 +716,6 @@ static hipError_t launch_fused(hx_engine *e, const FusedParams &p, uint32_t grid
     return hipGetLastError();
 }
 
-#ifdef HX_EXPERIMENTS
-template <class OP, int MODE>
-static hipError_t launch_fused2(hx_engine *e, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes)
-{
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        hipError_t s = hipFuncSetAttribute((const void *)k_fused2<OP, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (s != hipSuccess) return s;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_fused2<OP, MODE>), dim3(grid), dim3(1024), (size_t)nc * slot_bytes + 64, e->fused_stream ? e->fused_stream : e->stream, p, nc, slot_bytes);
-    return hipGetLastError();
-}
-template <class OP>
-static hipError_t launch_fused2_mode(hx_engine *e, const FusedParams &p, uint32_t grid, uint32_t nc, uint32_t slot_bytes, int mode)
-{
-    return mode == 0 ? launch_fused2<OP, 0>(e, p, grid, nc, slot_bytes) : launch_fused2<OP, 1>(e, p, grid, nc, slot_bytes);
-}
-
-#endif  // HX_EXPERIMENTS
 
 template <class OP, int LPR>
 static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t grid, size_t lds, int mode)
