@@ -89,6 +89,8 @@ __device__ __forceinline__ float fh_d(const uint2 &v) { return __builtin_bit_cas
 // touches a heap, and a thread sees its own stores in program order).  Deep heaps are rare and only their bottom level
 // spills, so the common case never leaves LDS while the LDS budget per search stays small.
 typedef __attribute__((address_space(3))) uint2 lds_uint2;     // LDS-qualified: keeps heap accesses ds_read/ds_write, never FLAT
+typedef __attribute__((address_space(3))) uint8_t lds_u8;       // a vector parked in LDS (query, select candidate): read with ds_read_b128 also where the pointer is picked at run time
+typedef __attribute__((address_space(3))) u4 lds_u4;
 struct HStore {
     lds_uint2 *lds; uint2 *glob; uint32_t L;
     __device__ __forceinline__ uint2 get(uint32_t i) const
@@ -308,7 +310,7 @@ __device__ __forceinline__ bool wt_lookup(const uint2 *tab, uint32_t mask, uint3
 
 struct FusedCtx {
     FRows fr;
-    uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; uint8_t *QV, *EV; HStore CH, WH;
+    uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; lds_u8 *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
     GStore DS; lds_uint2 *DP, *WS; uint32_t *LV; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
@@ -316,25 +318,25 @@ struct FusedCtx {
 };
 
 // parks one vector (row or query slot) in LDS, chunk-major: bytes [c*1024 + 16*lane, +16); zero past the pitch
-__device__ __forceinline__ void f_park(const FRows &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+__device__ __forceinline__ void f_park(const FRows &p, const uint8_t *src, uint32_t lane, lds_u8 *dst)
 {
     for (uint32_t c = 0; c < p.nch; c++) {
         const uint32_t off = c * 1024u + lane * 16u;
         u4 v = {0u, 0u, 0u, 0u};
         if (off < p.pitch) v = *(const u4 *)(src + off);
-        *(u4 *)(dst + off) = v;
+        *(lds_u4 *)(dst + off) = v;
     }
     F_BAR();
 }
 
 // f_park for code that runs in ONE wave of a multi-wave workgroup (no workgroup barrier)
-__device__ __forceinline__ void f_park_w(const FRows &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+__device__ __forceinline__ void f_park_w(const FRows &p, const uint8_t *src, uint32_t lane, lds_u8 *dst)
 {
     for (uint32_t c = 0; c < p.nch; c++) {
         const uint32_t off = c * 1024u + lane * 16u;
         u4 v = {0u, 0u, 0u, 0u};
         if (off < p.pitch) v = *(const u4 *)(src + off);
-        *(u4 *)(dst + off) = v;
+        *(lds_u4 *)(dst + off) = v;
     }
     F_WSYNC();
 }
@@ -342,14 +344,14 @@ __device__ __forceinline__ void f_park_w(const FRows &p, const uint8_t *src, uin
 // f_park without the trip through registers: gfx950's global_load_lds writes each lane's 16 bytes straight to
 // LDS (destination = wave-uniform base + 16 * lane: exactly the parked layout) and completes asynchronously under vmcnt, so the
 // NEXT select candidate's row travels while the current one is being compared.  Lanes past the row's end store zeros themselves.
-__device__ __forceinline__ void f_park_async(const FRows &p, const uint8_t *src, uint32_t lane, uint8_t *dst)
+__device__ __forceinline__ void f_park_async(const FRows &p, const uint8_t *src, uint32_t lane, lds_u8 *dst)
 {
     for (uint32_t c = 0; c < p.nch; c++) {
         const uint32_t off = c * 1024u + lane * 16u;
         if (off < p.pitch)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(src + off),
                                              (__attribute__((address_space(3))) uint32_t *)(dst + c * 1024u), 16, 0, 0);
-        else *(u4 *)(dst + off) = u4{0u, 0u, 0u, 0u};
+        else *(lds_u4 *)(dst + off) = u4{0u, 0u, 0u, 0u};
     }
 }
 
@@ -358,13 +360,13 @@ __device__ __forceinline__ void f_park_async(const FRows &p, const uint8_t *src,
 // are read by ONE load instruction, and up to eight such instructions are in flight, so a whole neighbour list is one hop.
 // The bits are the canonical ones: the lanes a short row does not reach contribute +0.0 partials in the 64-lane order.
 template <class OP, int LPR>
-__device__ __forceinline__ float f_dist_small(const FRows &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
+__device__ __forceinline__ float f_dist_small(const FRows &p, const lds_u8 *qv, const uint32_t *ids, uint32_t n, uint32_t lane)
 {
     constexpr int R = 64 / LPR, PF = 8;
     const uint32_t g = lane / LPR, loff = (lane % LPR) * 16u;
     const bool in = loff < p.pitch;
     u4 q = {0u, 0u, 0u, 0u};
-    if (in) q = *(const u4 *)(qv + loff);
+    if (in) q = *(const lds_u4 *)(qv + loff);
     for (uint32_t j0 = 0; j0 < n; j0 += R * PF) {
         u4 rv[PF];
 #pragma unroll
@@ -396,7 +398,7 @@ template <int LPR> __device__ __forceinline__ constexpr uint32_t f_step_rows() {
 // FUSED_RB rows x FUSED_CG 1-KiB chunks are requested at once (one HBM latency per row batch at d <= 768 f32), then
 // consumed chunk by chunk in ascending order -- the canonical per-lane order.
 template <class OP, int LPR, int RB = FUSED_RB>
-__device__ __forceinline__ float f_dist_batch(const FRows &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
+__device__ __forceinline__ float f_dist_batch(const FRows &p, const lds_u8 *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
     if constexpr (LPR < 64) return f_dist_small<OP, LPR>(p, qv, ids, n, lane);
     float mine = 0.0f;
@@ -444,7 +446,7 @@ __device__ __forceinline__ float f_dist_batch(const FRows &p, const uint8_t *qv,
 #pragma unroll
             for (int k = 0; k < FUSED_CG; k++) {
                 if ((uint32_t)k < kc) {
-                    const u4 q = *(const u4 *)(qv + (c0 + (uint32_t)k) * 1024u + loff);
+                    const u4 q = *(const lds_u4 *)(qv + (c0 + (uint32_t)k) * 1024u + loff);
                     if (ragged && c0 + (uint32_t)k + 1u == p.nch) {                 // the row's partial last chunk: lanes past the payload contribute zeros
 #pragma unroll
                         for (int r = 0; r < RB; r++) {
@@ -485,7 +487,7 @@ __device__ __forceinline__ float f_dist_batch(const FRows &p, const uint8_t *qv,
 // order and the scan stops at the first batch that contains a hit, like the reference's early `return false`
 // (the answer is the same; fewer rows are streamed for rejected candidates).  *n_eval += rows evaluated.
 template <class OP, int LPR>
-__device__ __forceinline__ bool f_any_le(const FRows &p, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
+__device__ __forceinline__ bool f_any_le(const FRows &p, const lds_u8 *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
                                          unsigned long long &n_eval)
 {
     constexpr uint32_t B = f_step_rows<LPR>();
@@ -501,13 +503,13 @@ __device__ __forceinline__ bool f_any_le(const FRows &p, const uint8_t *qv, cons
 
 // query-vs-rows distances of one expansion / one check_element_closer step
 template <class OP, int LPR, int RB = FUSED_RB>
-__device__ __forceinline__ float f_dist(FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
+__device__ __forceinline__ float f_dist(FusedCtx &cx, const lds_u8 *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
     return f_dist_batch<OP, LPR, RB>(cx.fr, qv, ids, n, lane, tk);
 }
 
 template <class OP, int LPR>
-__device__ __forceinline__ bool f_any_le_x(FusedCtx &cx, const uint8_t *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr, unsigned long long &n_eval)
+__device__ __forceinline__ bool f_any_le_x(FusedCtx &cx, const lds_u8 *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr, unsigned long long &n_eval)
 {
     return f_any_le<OP, LPR>(cx.fr, qv, ids, n, lane, thr, n_eval);
 }

@@ -444,7 +444,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
     cx.fr.dsc = (float *)(cx.CTL + 32);
     cx.RES = (uint2 *)(cx.fr.dsc + 64);
     cx.RL = cx.RES + 64;
-    cx.QV = (uint8_t *)(cx.RL + 64);                      // query parked in LDS (nch KiB)
+    cx.QV = (lds_u8 *)(cx.RL + 64);                       // query parked in LDS (nch KiB)
     cx.W = (uint2 *)(cx.QV + p.nch * 1024u);
     cx.EP = cx.W + (p.ef + 2);
     cx.C = cx.EP + (p.ef + 2);
@@ -452,7 +452,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
     cx.WS = cx.DP + 64; cx.LV = (uint32_t *)(cx.WS + 160);   // working set of a flush (<= 2*64 + depth entries), per-level {first index, offset}
     cx.DS.A = cx.WS + 160 + 32; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
     cx.DS.G = MODE == 2 ? p.disc + (size_t)slot * p.disc_stride : nullptr; cx.dlen = 0; cx.vcount = 0;
-    cx.EV = (uint8_t *)cx.C;                              // host guarantees clds*8 >= nch*1024 + (ef+2)*8
+    cx.EV = (lds_u8 *)cx.C;                               // host guarantees clds*8 >= nch*1024 + (ef+2)*8
     cx.DL = (uint2 *)(cx.EV + p.nch * 1024u);
     cx.CH.lds = (lds_uint2 *)cx.C; cx.CH.glob = p.spill + (size_t)slot * p.spill_stride; cx.CH.L = p.clds;
     cx.WH.lds = (lds_uint2 *)cx.W; cx.WH.glob = nullptr; cx.WH.L = 0xffffffffu;
@@ -634,7 +634,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
                     // Its neighbour list comes along: d(e, r) for an accepted r that is already one of e's neighbours is stored in
                     // the mirror (the very bits a fresh evaluation gives: every term is symmetric in its operands), so a candidate
                     // that one of those rules out costs no row traffic at all.
-                    uint8_t *const evb[2] = {cx.EV, cx.QV};
+                    lds_u8 *const evb[2] = {cx.EV, cx.QV};
                     uint32_t nx_id = 0xFFFFFFFFu; float nx_d = 0.0f;                  // lane's slot of the NEXT candidate's list (id, stored distance)
                     auto list_prefetch = [&](uint32_t el) {
                         const uint32_t *li; const float *ld; uint32_t lc_n;

@@ -248,7 +248,7 @@ k_pm_fill(const LinksParams p, float *pm, uint8_t *pm_valid)
 // that the new row is the one left out and every survivor keeps its slot (then list, distances and matrix stay as they are).
 template <class OP, int LPR, bool SPEC, int SLOTS = LC_SLOTS>   // SLOTS: list capacity the kernel is built for (32: m <= 16, 64: m <= 32); also the index that stands for the new row
 __device__ bool lc_op(const FRows &fp, const LinksParams &p, float *M, float *M2, uint32_t *lid, float *ld, uint32_t *lid2, float *ld2,
-                      float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, uint8_t *QV,
+                      float *nd, uint32_t *pos, float *sd, uint32_t *sel, uint32_t *dis, uint32_t *ORD, uint32_t *IDS, lds_u8 *QV,
                       uint32_t &cnt, uint32_t &v, const uint32_t lm, const uint32_t new_id, const float new_d, const uint32_t lane, unsigned long long &ndist, unsigned long long *tk = nullptr,
                       const uint2 *wt = nullptr, const uint32_t wt_mask = 0)
 {
@@ -425,7 +425,7 @@ k_links_cached(const LinksParams p, float *pm, uint8_t *pm_valid)
     float *sd = (float *)(pos + AR);
     uint32_t *sel = (uint32_t *)(sd + AR), *dis = sel + AR, *ORD = dis + AR, *IDS = ORD + AR;   // IDS[64]
     float *DSC = (float *)(IDS + 64);
-    uint8_t *QV = (uint8_t *)(DSC + 64);
+    lds_u8 *QV = (lds_u8 *)(DSC + 64);
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x >= p.n_groups) return;
     const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
@@ -495,7 +495,7 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
     float *nd = (float *)wbase; uint32_t *pos = (uint32_t *)(nd + AR); float *sd = (float *)(pos + AR);
     uint32_t *sel = (uint32_t *)(sd + AR), *dis = sel + AR, *ORD = dis + AR, *IDS = ORD + AR;
     float *DSC = (float *)(IDS + 64);
-    uint8_t *QV = (uint8_t *)(DSC + 64);
+    lds_u8 *QV = (lds_u8 *)(DSC + 64);
     if (blockIdx.x >= p.n_groups) return;
     const uint32_t g = p.gmap ? p.gmap[blockIdx.x] : blockIdx.x;
     const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC};
