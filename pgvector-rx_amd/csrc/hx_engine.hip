@@ -475,7 +475,7 @@ int hx_destroy(hx_engine *e)
     HxMirror &mr = e->mirror;
     void *hp[] = {c.h_req, c.h_res, mr.h_stage, mr.io.h_io, mr.h_lk, e->grp.h_ctr, e->grp.h, e->bw.h, e->bw.h_ctr};
     void *dp[] = {c.d_req, c.d_res, e->d_rows, e->d_queries, mr.d_l0_ids, mr.d_l0_d, mr.d_l0_cnt, mr.d_level, mr.d_up_block, mr.d_up_ids, mr.d_up_d, mr.d_up_cnt, mr.io.d_vis, mr.d_stage, mr.io.d_io, mr.d_lk, mr.d_pm, mr.d_pm_valid, mr.io.d_spill,
-                  mr.d_disc, mr.d_emask, mr.d_spill_big, mr.d_vis_big, e->grp.d, e->bw.d, e->bw.d_rec, e->d_xl, e->bw.d_wtab, e->bw.d_wt_valid, e->d_mf_norm2};
+                  mr.d_disc, mr.d_emask, mr.d_spill_big, mr.d_vis_big, e->grp.d, e->bw.d, e->bw.d_rec, e->d_xl, e->bw.d_wtab, e->bw.d_wt_valid, e->d_mf_norm2, e->d_wg, e->wsel.d_wl, e->wsel.d_cnt, e->wsel.d_slot, e->wsel.d_task, e->wsel.d_layer, e->wsel.d_counters};
     for (void *p : hp) if (p) (void)hipHostFree(p);
     for (void *p : dp) if (p) (void)hipFree(p);
     for (HxFusedIo &io : e->scan_io) {                           // pipelined scan slots: a launch still in flight is drained first

@@ -177,9 +177,11 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     if (io.busy) return fail(HX_E_STATE, "a launch is still in flight on this slot");
     if (ntasks == 0) return fail(HX_E_ARG, "no tasks");
     if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_ARG, "row too wide for the fused kernel");
-    if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
+    const bool ins = mode == 1 || mode == 3;                       // find_element_neighbors (3: search only, W lists out)
+    if (ins && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
+    if (mode == 3 && (!dev || !dev->d_wl_out || !dev->d_wl_cnt || !dev->h_prob)) return fail(HX_E_ARG, "mode 3 needs the W-list buffers");
     if (mode == 2 && (!it || !it->emask || !it->out_tix)) return fail(HX_E_ARG, "iterative scan arguments missing");
-    if (dev && mode != 1) return fail(HX_E_ARG, "device-resident results are an insert-mode feature");
+    if (dev && !ins) return fail(HX_E_ARG, "device-resident results are an insert-mode feature");
     HX_HIP(this, hipSetDevice(device));
     // LDS (carved in hx_fused_kernel.h f_worker): IDS[64] CTL[32] dsc[64] (4 B each) | RES[64] RL[64] (8 B each) | query (nch KiB) | W[ef+2] EP[ef+2] C[clds] (8 B each)
     // candidate heap: up to FUSED_CCAP entries, the first `clds` in LDS and the tail in a per-workgroup spill area
@@ -188,22 +190,23 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     const size_t nch_ = (pitch + 1023) / 1024;
     if (roomy < 1) roomy = 1;
     const uint32_t ccap = FUSED_CCAP * roomy;
-    uint32_t clds = mode == 1 ? 600u : 512u;     // insert: 600 entries measured +8 % over 1024 (13 instead of 10 searches per CU at ef_construction 200)
+    uint32_t clds = ins ? 600u : 512u;     // insert: 600 entries measured +8 % over 1024 (13 instead of 10 searches per CU at ef_construction 200)
     uint32_t disc_lds = mode == 2 ? 512u : 0u;
     uint32_t iter_per_cu = 14u;
     if (mode == 2) { const char *a = getenv("HX_DISC_LDS"), *b = getenv("HX_ITER_PER_CU"); if (a && atoi(a) > 0) disc_lds = (uint32_t)atoi(a); if (b && atoi(b) > 0) iter_per_cu = (uint32_t)atoi(b); }   // tuning knobs
-    { const char *cv = getenv(mode == 1 ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
+    { const char *cv = getenv(ins ? "HX_CLDS_INSERT" : "HX_CLDS_QUERY"); if (cv && atoi(cv) > 0) clds = (uint32_t)atoi(cv); }   // tuning knob
     // HX_SORTED_ARRAY=1 (opt-in experiment, hx_fused_kernel.h: f_search_layer_sa): first launches of queries search on one sorted array; a query that
     // meets a tie reports FS_OVERFLOW and its retry launch (roomy > 1) uses the heap kernel, which is exact for any input
     const int sa_env = sa_env_on();
     const bool sa = sa_env && roomy == 1 && mode == 0 && dtype != HX_BIT && ef > 1 && ef <= 256;
     if (sa) clds = 0;                                            // no candidate heap
-    if (mode == 1) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // select scratch aliases C's LDS part
+    if (mode == 1) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // (mode 3 has no select phase)
+      // select scratch aliases C's LDS part
     if (dev && dev->d_wtab) clds = std::max<uint32_t>(clds, dev->wt_size);                     // so does the W table
     auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 64) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };   // f_worker's carve
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
-    const size_t waves_cap = 4u * (size_t)(mode == 2 ? FUSED_MINW_ITER : mode == 1 ? FUSED_MINW_INS : FUSED_MINW);   // register-file limit: launch_bounds waves per SIMD x 4 SIMDs
+    const size_t waves_cap = 4u * (size_t)(mode == 2 ? FUSED_MINW_ITER : ins ? FUSED_MINW_INS : FUSED_MINW);   // register-file limit: launch_bounds waves per SIMD x 4 SIMDs
     uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max<size_t>(16, waves_cap), (160 * 1024) / (lds + 512)));
     { const char *pv = getenv(mode == 0 ? "HX_QUERY_PER_CU" : "HX_INSERT_PER_CU"); if (mode != 2 && pv && atoi(pv) > 0) per_cu = std::min<uint32_t>(per_cu, (uint32_t)atoi(pv)); }   // tuning knob
     per_cu = std::min<uint32_t>(per_cu, FUSED_SLOTS_PER_CU);
@@ -260,10 +263,10 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
         io.cap_vis = n;
     }
     // dev: the neighbour lists go straight into the caller's device records (a batch's exchange buffer); only the statuses come back
-    const size_t out_n = dev ? 0 : mode != 1 ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;      // mode 2: k = limit
-    const size_t cnt_n = dev ? 0 : mode != 1 ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
+    const size_t out_n = dev ? 0 : !ins ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;      // mode 2: k = limit
+    const size_t cnt_n = dev ? 0 : !ins ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
     // device task/in/out buffers (one allocation, reused)
-    const size_t need = al16((size_t)ntasks * 4) * 4 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
+    const size_t need = al16((size_t)ntasks * 4) * 5 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
     if (need > io.cap_io) {
         if (io.d_io) (void)hipFree(io.d_io);
         if (io.h_io) (void)hipHostFree(io.h_io);
@@ -278,6 +281,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     const size_t o_q = o; o += al16((size_t)ntasks * 4);
     const size_t o_lv = o; o += al16((size_t)ntasks * 4);
     const size_t o_slot = o; o += al16((size_t)ntasks * 4);
+    const size_t o_prob = o; o += al16((size_t)ntasks * 4);
     const size_t in_bytes = o;
     const size_t o_st = o; o += al16((size_t)ntasks * 4);
     const size_t o_cnt = o; o += al16(cnt_n * 4);
@@ -288,6 +292,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     memcpy(io.h_io + o_q, q_sel, (size_t)ntasks * 4);
     if (t_level) memcpy(io.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(io.h_io + o_lv, 0, (size_t)ntasks * 4);
     if (dev && dev->h_slots) memcpy(io.h_io + o_slot, dev->h_slots, (size_t)ntasks * 4);
+    if (mode == 3) memcpy(io.h_io + o_prob, dev->h_prob, (size_t)ntasks * 4);
     HX_HIP(this, hipMemcpyAsync(io.d_io, io.h_io, in_bytes, hipMemcpyHostToDevice, stream));
     FusedParams p;
     p.rows = d_rows; p.queries = d_queries; p.pitch = (uint32_t)pitch; p.nch = (uint32_t)((pitch + 1023) / 1024); p.n_rows = n_rows;
@@ -308,6 +313,8 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     p.status = (uint32_t *)(io.d_io + o_st);
     p.o_cst = FUSED_MAXL; p.o_lst = FUSED_MAXL * 2 * mr.m; p.t_oslot = nullptr;
     p.wtab = nullptr; p.wt_size = 0; p.wt_slot0 = 0; p.wt_valid = nullptr;
+    p.wl_out = nullptr; p.wl_cnt = nullptr; p.t_prob = nullptr;
+    if (mode == 3) { p.wl_out = (uint2 *)dev->d_wl_out; p.wl_cnt = dev->d_wl_cnt; p.t_prob = (const uint32_t *)(io.d_io + o_prob); }
     if (dev && dev->d_wtab) { p.wtab = (uint2 *)dev->d_wtab; p.wt_size = dev->wt_size; p.wt_slot0 = dev->wt_slot0; p.wt_valid = dev->d_wt_valid; }
     if (dev) {   // record = cnt[FUSED_MAXL] | ids[FUSED_MAXL][2m] | d[FUSED_MAXL][2m]  (hx_batch.hip reads the same layout)
         p.out_cnt = dev->d_rec; p.out_ids = dev->d_rec + FUSED_MAXL; p.out_d = (float *)(dev->d_rec + FUSED_MAXL + FUSED_MAXL * 2 * mr.m);

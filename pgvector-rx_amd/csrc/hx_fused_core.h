@@ -53,6 +53,9 @@ struct FusedParams {
     const uint32_t *t_oslot;                      // MODE 1: output slot s of task t (nullptr: s = t)
     uint2 *wtab; uint32_t wt_size, wt_slot0; uint8_t *wt_valid;   // MODE 1: the layer-0 result set W of task t as an open-addressing table of wt_size {d, id} entries at
                                                   // wtab + (wt_slot0 + s) * wt_size (the back-link kernels look d(new row, x) up there instead of streaming row x); nullptr: off
+    // MODE 3 (insert, search only: select_neighbors runs on the matrix cores afterwards, hx_mfma.hip): the sorted result set W of layer lc of task t goes to
+    // problem t_prob[t] + lc: wl_out[problem * ef + i] = {distance bits, id}, wl_cnt[problem] = |W|
+    uint2 *wl_out; uint32_t *wl_cnt; const uint32_t *t_prob;
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
     // iterative scan (k_fused MODE 2): hnsw.iterative_scan relaxed_order (1) / strict_order (2), scan.rs:794-875
     uint32_t iter_mode, limit; long long max_tuples;

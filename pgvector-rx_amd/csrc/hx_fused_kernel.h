@@ -434,6 +434,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
 {
     FusedCtx cx;
     KParams &p = f_params_here(p_in);
+    constexpr bool INS = MODE == 1 || MODE == 3;           // find_element_neighbors; MODE 3 stops after each layer's search (select on the matrix cores)
     const uint32_t lm0 = 2u * p.m;
     // LDS carve, fixed-size regions first so that their addresses are compile-time constants (no scalar register holds them):
     //   IDS[64] u32 | CTL[32] u32 | dsc[64] f32 | RES[64] | RL[64] | QV[nch KiB] | W[ef+2] | EP[ef+2] | C[clds] | MODE 2: DP[64] WS[160] LV[32] DS[disc_lds]
@@ -474,11 +475,11 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
         const uint32_t qsel = p.t_qsel[t];
         const uint8_t *qsrc = (qsel & HX_QUERY_SLOT) ? p.queries + (size_t)(qsel & 0x7fffffffu) * p.pitch : p.rows + (size_t)qsel * p.pitch;
         f_park(cx.fr, qsrc, lane, cx.QV);
-        const int new_level = MODE == 1 ? p.t_level[t] : -1;
+        const int new_level = INS ? p.t_level[t] : -1;
         // MODE 1 outputs are addressed through strides so that one launch can fill either the SoA staging arrays or the AoS records
         // of a batch's exchange buffer (hx_batch.hip); os = output slot of this task
-        const uint32_t os = (MODE == 1 && p.t_oslot) ? p.t_oslot[t] : t;
-        if (MODE == 1 && new_level >= FUSED_MAXL) { if (lane == 0) p.status[t] = FS_HOST; continue; }
+        const uint32_t os = (INS && p.t_oslot) ? p.t_oslot[t] : t;
+        if (INS && new_level >= FUSED_MAXL) { if (lane == 0) p.status[t] = FS_HOST; continue; }
 
         // d(q, entry point): mod.rs:371-377 / scan.rs:475
         if (lane == 0) cx.IDS[0] = p.entry;
@@ -490,23 +491,23 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
         uint32_t n_ep = 1;
 
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
-        const int stop_above = MODE == 1 ? new_level : 0;
+        const int stop_above = INS ? new_level : 0;
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
 #ifdef HX_EXPERIMENTS
             if constexpr (SA) {
                 f_search_layer_sa<OP, LPR>(p, cx, n_ep, 1u, lc);
                 if (cx.CTL[1] > 0) { const uint2 best = cx.W[0]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); n_ep = 1; }
-                else if (MODE != 1) { n_ep = 0; break; }
+                else if (!INS) { n_ep = 0; break; }
                 continue;
             }
 #endif
-            f_search_layer<OP, LPR, false>(p, cx, n_ep, 1u, lc, MODE != 1);
+            f_search_layer<OP, LPR, false>(p, cx, n_ep, 1u, lc, !INS);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
-                f_sort_results(cx, wl, MODE != 1);
-                if (MODE != 1) { const uint2 best = cx.EP[wl - 1]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); }
+                f_sort_results(cx, wl, !INS);
+                if (!INS) { const uint2 best = cx.EP[wl - 1]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); }
                 n_ep = 1;                         // MODE 1: ep = vec![w[0]]; EP[0] already is the nearest
-            } else if (MODE != 1) { n_ep = 0; break; }
+            } else if (!INS) { n_ep = 0; break; }
         }
 
         if (MODE == 2) {
@@ -621,6 +622,14 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
                     if (lane == 0 && p.wt_valid) p.wt_valid[p.wt_slot0 + os] = 1;
                     F_BAR();
                 }
+                if constexpr (MODE == 3) {                                           // W (ascending) leaves the kernel; select_neighbors follows in hx_mfma.hip
+                    const size_t pr = (size_t)p.t_prob[t] + (size_t)lc;
+                    uint2 *dst = p.wl_out + pr * p.ef;
+                    for (uint32_t i = lane; i < wl; i += 64) dst[i] = cx.EP[i];
+                    if (lane == 0) p.wl_cnt[pr] = wl;
+                    F_BAR();
+                    continue;
+                }
                 // select_neighbors(W, lm): mod.rs:269-308
                 const unsigned long long ts0 = (FUSED_TIMERS_ON && (p.fdbg & 4u)) ? __builtin_amdgcn_s_memtime() : 0ull;
                 uint32_t r = 0, nd = 0;
@@ -688,7 +697,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
 }
 
 template <class OP, int MODE, int LPR, bool SA = false>
-__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : MODE == 1 ? FUSED_MINW_INS : SA ? FUSED_MINW_SA : FUSED_MINW))
+__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : (MODE == 1 || MODE == 3) ? FUSED_MINW_INS : SA ? FUSED_MINW_SA : FUSED_MINW))
 k_fused(const FusedParams p_unused)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -724,6 +733,8 @@ static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t 
 #ifdef HX_EXPERIMENTS
     if constexpr (OP::sorted_array_ok) { if (p.sa && mode == 0) return launch_fused<OP, 0, LPR, true>(e, p, grid, lds); }
 #endif
+    if constexpr (OP::mfma_split_ok && LPR == 64) { if (mode == 3) return launch_fused<OP, 3, LPR>(e, p, grid, lds); }
+    if (mode == 3) return hipErrorInvalidValue;          // the host only asks for it where it is built (halfvec inner product, rows > 512 B)
     return mode == 0 ? launch_fused<OP, 0, LPR>(e, p, grid, lds) : launch_fused<OP, 1, LPR>(e, p, grid, lds);
 }
 template <class OP>

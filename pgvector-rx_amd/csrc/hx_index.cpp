@@ -1521,6 +1521,39 @@ int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_recor
     if (ix->e->bw.wt_size) { dev.d_wtab = ix->e->bw.d_wtab; dev.wt_size = ix->e->bw.wt_size; dev.wt_slot0 = lo; dev.d_wt_valid = ix->e->bw.d_wt_valid; }
     int rc;
     const double t0 = hx_index::now_s();
+    // halfvec inner product with hx_index_set_mfma(1): the traversal kernel stops after each layer's search (MODE 3) and select_neighbors runs on the
+    // matrix cores (hx_mfma.hip: k_wgemm_f16 + k_wselect) -- SURVEY 8 row g on the default placement.  Same lists, same distance bits.
+    const bool split = ix->mfma_on() && ix->efc <= 256 && ix->e->pitch > 512;
+    if (split) {
+        hx_engine *e = ix->e;
+        if ((rc = e->mfma_norms(e->n_rows))) return ix->fail(rc, e->err);
+        std::vector<uint32_t> prob(n), pslot, ptask; std::vector<uint8_t> player;
+        for (uint32_t k = 0; k < n; k++) {
+            prob[k] = (uint32_t)player.size();
+            const int start = std::min<int>(tl[k], bs.entry_level);
+            for (int lc = 0; lc <= start; lc++) { player.push_back((uint8_t)lc); pslot.push_back(slots[k]); ptask.push_back(k); }
+        }
+        const uint32_t P = (uint32_t)player.size();
+        if ((rc = e->wsel_reserve(P, (uint32_t)ix->efc))) return ix->fail(rc, e->err);
+        HxWselWork &w = e->wsel;
+        if (hipMemcpyAsync(w.d_layer, player.data(), P, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemcpyAsync(w.d_slot, pslot.data(), (size_t)P * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemcpyAsync(w.d_task, ptask.data(), (size_t)P * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+            hipMemsetAsync(w.d_cnt, 0, (size_t)P * 4, e->stream) != hipSuccess || hipMemsetAsync(w.d_counters, 0, 32, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess) return ix->fail(HX_E_HIP, "matrix-core select: staging the problem table failed");
+        dev.d_wl_out = w.d_wl; dev.d_wl_cnt = w.d_cnt; dev.h_prob = prob.data();
+        if ((rc = e->fused_run(3, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
+                               nullptr, nullptr, nullptr, tstat.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, e->err);
+        const uint32_t *d_status = (const uint32_t *)(e->mirror.io.d_io + e->mirror.io.o_st);      // the launch's statuses stay there until the next launch
+        if ((rc = e->mfma_select(P, (uint32_t)ix->efc, w.d_wl, w.d_cnt, w.d_layer, w.d_slot, w.d_task, d_status, dev.d_rec, rw, w.d_counters))) return ix->fail(rc, e->err);
+        unsigned long long wc[4] = {0, 0, 0, 0};
+        if (hipMemcpyAsync(wc, w.d_counters, 32, hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+            return ix->fail(HX_E_HIP, "matrix-core select failed");
+        if ((rc = e->mfma_select_done(wc[2]))) return ix->fail(rc, e->err);
+        ix->mfma_pairs += wc[0]; ix->mfma_exact += wc[1];
+        cnts[1] += wc[1];                                          // select distances evaluated by streaming rows (the canonical re-evaluations)
+        dev.d_wl_out = nullptr; dev.d_wl_cnt = nullptr; dev.h_prob = nullptr;   // the overflow retry below is a plain MODE 1 launch
+    } else
     if ((rc = ix->e->fused_run(1, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
                                nullptr, nullptr, nullptr, tstat.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, ix->e->err);
     for (uint32_t k = 0; k < n; k++) status[slots[k]] = tstat[k];

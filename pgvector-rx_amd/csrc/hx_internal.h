@@ -79,7 +79,9 @@ struct HxMirror {
 // insert-mode results written straight into device records (a batch's exchange buffer, hx_batch.hip): record r =
 // cnt[HX_FUSED_MAXL] | ids[HX_FUSED_MAXL][2m] | d[HX_FUSED_MAXL][2m], rec_words 32-bit words apart; task t fills record h_slots[t] (nullptr: t)
 struct HxFusedDev { uint32_t *d_rec = nullptr; uint32_t rec_words = 0; const uint32_t *h_slots = nullptr;
-                    void *d_wtab = nullptr; uint32_t wt_size = 0, wt_slot0 = 0; uint8_t *d_wt_valid = nullptr; };   // W tables of the members (hx_fused_core.h FusedParams::wtab)
+                    void *d_wtab = nullptr; uint32_t wt_size = 0, wt_slot0 = 0; uint8_t *d_wt_valid = nullptr;
+                    // mode 3 (search only; hx_mfma.hip selects): layer lc of task t is problem h_prob[t] + lc; its W goes to d_wl_out[problem * ef ..], |W| to d_wl_cnt[problem]
+                    void *d_wl_out = nullptr; uint32_t *d_wl_cnt = nullptr; const uint32_t *h_prob = nullptr; };   // W tables of the members (hx_fused_core.h FusedParams::wtab)
 
 // device-side grouping of a batch's back-link ops (hx_group.hip): workspace + the grouped arrays it leaves on the device
 struct HxGroupWork {
@@ -96,6 +98,9 @@ struct HxBatchWork {
     uint32_t wt_size = 0, wt_base = 0, wt_n = 0;        // entries per table (0: off); element ids [wt_base, wt_base + wt_n) are the open batch's members
 };
 uint32_t hx_rec_words(uint32_t m);                      // 32-bit words per member record: cnt[HX_FUSED_MAXL] | ids[HX_FUSED_MAXL][2m] | d[HX_FUSED_MAXL][2m]
+// W lists and problem table of a k_fused MODE 3 launch (hx_mfma.hip)
+struct HxWselWork { void *d_wl = nullptr; uint32_t *d_cnt = nullptr, *d_slot = nullptr, *d_task = nullptr; uint8_t *d_layer = nullptr; unsigned long long *d_counters = nullptr;
+                    size_t cap_prob = 0; uint32_t cap_ef = 0; };
 struct hx_engine;
 static inline uint32_t hx_xrec_words(uint32_t m) { return (3u + 4u * m + 3u) & ~3u; }   // list record of the multi-GPU exchange: target, layer, cnt, ids[2m], d[2m]
 int hx_group_stage(hx_engine *e, uint32_t n_ops, HxGroupWork &w, unsigned long long **keys, uint32_t **op_new, float **op_d);
@@ -121,6 +126,11 @@ struct hx_engine {
     // |row|^2 of halfvec rows for the MFMA band (hx_mfma.hip)
     float *d_mf_norm2 = nullptr; uint64_t mf_cap = 0, mf_norm_rows = 0; std::vector<float> h_mf_norm2;
     int mfma_norms(uint64_t upto);
+    HxWselWork wsel; int wsel_reserve(uint32_t n_prob, uint32_t ef); int mfma_select_done(uint64_t gemm_pairs);
+    // select_neighbors on the matrix cores behind k_fused MODE 3 (hx_mfma.hip): Gram matrices of the problems' candidates, then the heuristic on them
+    float *d_wg = nullptr; size_t cap_wg = 0; bool wg_pending = false;
+    int mfma_select(uint32_t n_prob, uint32_t ef, const void *d_wl, const uint32_t *d_wl_cnt, const uint8_t *d_prob_layer, const uint32_t *d_prob_slot,
+                    const uint32_t *d_prob_task, const uint32_t *d_status, uint32_t *d_rec, uint32_t rec_words, unsigned long long *d_counters);
     HxMirror mirror;
     uint64_t fused_cmax = 0;      // largest candidate-heap length any fused task reached (sizing the LDS budget)
     HxChannel ch;

@@ -82,6 +82,7 @@ template <int KIND> __device__ __forceinline__ void fterm(float &acc, float x, f
 }
 
 template <int KIND> struct OpF32 {
+    static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = true;    // real-valued distances: ties are rare enough for k_fused's sorted-array searches
     typedef float acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
@@ -100,6 +101,7 @@ template <int KIND> struct OpF32 {
 };
 
 template <int KIND> struct OpF16 {
+    static constexpr bool mfma_split_ok = KIND == K_IP;   // k_fused MODE 3: select_neighbors on the matrix cores (halfvec inner product is a true f16 GEMM)
     static constexpr bool sorted_array_ok = true;
     typedef float acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
@@ -121,6 +123,7 @@ template <int KIND> struct OpF16 {
 };
 
 struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
+    static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = false;   // integer-valued: ties everywhere, the heap kernels only
     typedef int acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a = 0; }
@@ -136,6 +139,7 @@ struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
 
 struct JacAcc { int ab, aa, bb; };
 struct OpJaccard {   // bitvec.rs:113-132
+    static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = false;
     typedef JacAcc acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a.ab = a.aa = a.bb = 0; }

@@ -80,3 +80,38 @@ def test_mfma_is_refused_for_other_types():
         ix.set_mfma(True)
     ix.close()
     e.close()
+
+
+@pytest.mark.parametrize("dim,n,m,efc,batch,signed", [(4000, 1200, 16, 200, 128, False), (4000, 700, 16, 200, 64, True), (1000, 1500, 8, 64, 100, False),
+                                                      (300, 2500, 32, 256, 200, True), (2000, 600, 16, 40, 50, False)])
+def test_graph_identical_to_oracle_with_the_fused_placement_and_mfma_on(dim, n, m, efc, batch, signed):
+    """The DEFAULT (device-resident) placement with hx_index_set_mfma(1): k_fused MODE 3 searches, k_wgemm_f16 computes each member's W x W Gram matrix
+    on the matrix cores (C4 shape: halfvec(4000), m 16, ef_construction 200 -> 7 x 7 tiles), k_wselect replays select_neighbors on it and re-evaluates
+    the in-band decisions in the canonical order.  Lists, distance bits, duplicates and entry point equal the oracle's; nothing falls to the
+    lock-step driver.  Signed rows make inner products cancel (values near the thresholds: the band logic is exercised hard)."""
+    rng = np.random.default_rng(dim + n)
+    vals = 2.0 * rng.random((n, dim)) * rng.random((n, dim))
+    if signed:
+        vals *= np.where(rng.random((n, dim)) < 0.5, -1.0, 1.0)
+    rows = vals.astype(np.float16).view(np.uint16)
+    rows[n // 2] = rows[5]
+    levels = hx.draw_levels(n, m, seed=31)
+    e = hx.Engine(hx.F16, hx.NEG_IP, dim, n)
+    e.append(rows)
+    e.set_timing(True)
+    ix = hx.Index(e, m, efc)
+    ix.set_mfma(True)                                   # fused placement stays on (the default)
+    ix.insert(0, levels, batch=batch)
+    st, ks = ix.mfma_stats(), e.kernel_stats(4)
+    assert st["mfma_pairs"] > 0 and ks["launches"] > 0 and ks["units"] > 0        # the GEMM ran
+    assert ix.fused_stats()["redone"] == 0 and ix.profile()["rounds"] == 0        # and nothing ran in the lock-step driver
+    print("\ndecisions from the matrix %d, pairs re-evaluated in the canonical order %d (%.2f %%); GEMM pairs %d in %.2f ms" % (
+        st["mfma_pairs"], st["exact_pairs"], 100.0 * st["exact_pairs"] / st["mfma_pairs"], ks["units"], ks["ms"]))
+    o = orc.Index(orc.F16, orc.NEG_IP, dim, m=m, ef_construction=efc, order=orc.W64)
+    i = 0
+    for b in hx.batch_schedule(0, n, batch):
+        o.insert_batch(rows[i:i + b], levels[i:i + b], np.arange(i, i + b))
+        i += b
+    assert_same_graph(ix, o, n)
+    ix.close()
+    e.close()
