@@ -149,7 +149,8 @@ int hx_set_timing(hx_engine *e, int enabled);
 int hx_last_kernel_ms(hx_engine *e, float *ms);
 /* Accumulated since the last reset, while timing is enabled: kind 0 = query-vs-rows kernel (units =
  * distances), kind 1 = pair-block kernel (units = pairs), 2 = traversal kernel, 3 = back-link kernels, 4 = MFMA pair kernel (units = pairs),
- * 5 = pipelined scans (hx_index_search_submit): units = distances, ms = the UNION of the overlapping launches' busy intervals. */
+ * 5 = pipelined scans (hx_index_search_submit): units = distances, ms = the UNION of the overlapping launches' busy intervals,
+ * 6 = select_neighbors on the Gram matrices of the matrix-core build path (k_wselect; kind 4 then is its GEMM, k_wgemm_f16). */
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset);
 
 /* ------------------------------------------------------------------------------------------------
@@ -262,8 +263,12 @@ int hx_index_counters(const hx_index *ix, uint64_t counters_out[8]);
  * lock-step host driver.  disabled: everything runs in the lock-step driver.  Both produce identical results.
  * fused_stats: tasks given to the fused kernel and how many of them had to be re-run. */
 int hx_index_set_fused(hx_index *ix, int enabled);
-/* Lock-step placement, halfvec inner product: pair blocks of select_neighbors / back-link pruning on the matrix cores (hx_pairwise_many_mfma),
- * in-band decisions re-evaluated in the canonical order.  stats: pairs evaluated by MFMA, pairs re-evaluated exactly. */
+/* halfvec inner product (BASELINE configs[3]): select_neighbors' candidate-vs-candidate distances (graph/mod.rs:284-297, 324-336 over halfvec.rs:687-733)
+ * are a true f16 GEMM and run on the matrix cores -- ON by default for that operator class, refused for every other.  Device-resident placement (default):
+ * the traversal kernel stops after each layer's search, k_wgemm_f16 computes each member's W x W Gram matrix (W <= ef_construction <= 256; larger
+ * ef_construction keeps the VALU select), k_wselect replays the heuristic on it.  Lock-step placement: pair blocks of select_neighbors / back-link pruning
+ * through hx_pairwise_many_mfma.  Either way a decision whose two sides lie within the summation-order band 2 dim 2^-24 |a||b| is re-evaluated in the
+ * canonical order, so lists and distance bits do not depend on the setting.  stats: decisions taken from MFMA values, pairs re-evaluated exactly. */
 int hx_index_set_mfma(hx_index *ix, int enabled);
 int hx_index_mfma_stats(const hx_index *ix, uint64_t *mfma_pairs, uint64_t *exact_pairs);
 int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone);

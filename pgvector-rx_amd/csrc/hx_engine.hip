@@ -796,7 +796,7 @@ int hx_last_kernel_ms(hx_engine *e, float *ms) { if (!e || !ms) return HX_E_ARG;
 int hx_kernel_stats(hx_engine *e, int kind, uint64_t *launches, uint64_t *units, double *ms, int reset)
 {
     if (!e) return HX_E_ARG;
-    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : kind == 2 ? e->stat_fused : kind == 3 ? e->stat_links : kind == 5 ? e->stat_scan : e->stat_mfma;
+    HxKernelStat &s = kind == 0 ? e->stat_dist : kind == 1 ? e->stat_pair : kind == 2 ? e->stat_fused : kind == 3 ? e->stat_links : kind == 5 ? e->stat_scan : kind == 6 ? e->stat_wsel : e->stat_mfma;
     if (kind == 5 && reset) { e->scan_epoch_set = false; e->scan_last_end = 0.0; }
     if (launches) *launches = s.launches;
     if (units) *units = s.units;

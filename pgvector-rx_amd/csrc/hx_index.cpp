@@ -1038,6 +1038,7 @@ int hx_index_create(hx_engine *e, int m, int ef_construction, hx_index **out)
     hx_index *ix = new (std::nothrow) hx_index();
     if (!ix) return e->fail(HX_E_NOMEM, "out of host memory");
     ix->e = e; ix->g.m = m; ix->efc = ef_construction;
+    ix->mfma = e->dtype == HX_F16 && e->metric == HX_NEG_IP;      // halfvec inner product: select_neighbors' pair distances are a true f16 GEMM -> matrix cores (hx_index_set_mfma(0): VALU)
     int nt = (int)std::thread::hardware_concurrency(); if (nt <= 0) nt = 4; if (nt > 16) nt = 16;
     ix->n_threads = nt; ix->pool.reset(new Pool(nt - 1));
     *out = ix;

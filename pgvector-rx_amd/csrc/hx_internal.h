@@ -118,7 +118,7 @@ struct hx_engine {
     hipStream_t fused_stream = nullptr;   // the stream the k_fused launchers use (set by fused_launch: the engine's, or a pipelined scan slot's)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     bool timing = false; float last_ms = 0.f;
-    HxKernelStat stat_dist, stat_pair, stat_fused, stat_links, stat_mfma;
+    HxKernelStat stat_dist, stat_pair, stat_fused, stat_links, stat_mfma, stat_wsel;
     // pipelined scans: launches overlap, so their busy time is the UNION of the launches' [start, end] intervals (HIP events of each slot's stream,
     // measured from ev_scan_epoch on the engine's stream); stat_scan.ms = that union
     HxKernelStat stat_scan; hipEvent_t ev_scan_epoch = nullptr; bool scan_epoch_set = false; double scan_last_end = 0.0;

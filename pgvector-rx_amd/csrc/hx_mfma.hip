@@ -111,7 +111,7 @@ __global__ void k_row_norm2_f16(const uint8_t *__restrict__ rows, uint32_t pitch
 // of ~310 flop/B, so the kernel is bound by streaming the W rows once -- 1.6 MB per problem at halfvec(4000)).
 //
 //   k_wgemm_f16   one 512-thread workgroup per problem: the n rows stream through LDS in K-chunks of 64 halves (128 B per row per chunk, fetched by
-//                 LDS-DMA with a per-lane source address: one wave instruction fills 8 rows), double-buffered; the lower-triangular 32 x 32 tiles
+//                 LDS-DMA with a per-lane source address: one wave instruction fills 8 rows), a ring of three chunk images (two in flight); the lower-triangular 32 x 32 tiles
 //                 (<= 36 at n <= 256) are dealt to the 8 waves in row-major runs (consecutive tiles share their A rows), v_mfma_f32_32x32x16_f16,
 //                 accumulators in registers for the whole K loop; -acc goes to G[problem][i (i - 1) / 2 + j], j < i.
 //                 LDS image of a chunk: row r at r * 128 B, its 16-byte piece kp in slot kp ^ ((r >> 1) & 7): the 16 lanes that one ds_read_b128
@@ -130,12 +130,13 @@ struct WgParams {
     const uint8_t *rows; uint32_t pitch, ef, m;
     const uint2 *wl; const uint32_t *wl_cnt; const uint8_t *prob_layer; uint32_t n_prob;
     float *G; uint64_t g_stride;                 // floats per problem: ef (ef - 1) / 2
+    uint32_t stage_bytes;                        // LDS bytes of one K-chunk image: round_up(ef, 8) rows x WG_KC (tile rows past it read the next stage / the pad: never stored)
 };
 
 __global__ void __launch_bounds__(512, 2)
 k_wgemm_f16(const WgParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // two stages of WG_NR x WG_KC bytes
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // a ring of three chunk images of stage_bytes each + a pad of 31 rows
     const uint32_t pr = blockIdx.x;
     const uint32_t n = p.wl_cnt[pr];
     const uint32_t lm = p.prob_layer[pr] == 0 ? 2u * p.m : p.m;
@@ -157,7 +158,7 @@ k_wgemm_f16(const WgParams p)
     }
     const uint32_t nchunks = (p.pitch + WG_KC - 1u) / WG_KC;
     auto dma = [&](uint32_t c) {
-        uint8_t *stage = lds + (c & 1u) * (WG_NR * WG_KC);
+        uint8_t *stage = lds + (c % 3u) * p.stage_bytes;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if ((uint32_t)j < my_grps) {                           // wave-uniform
@@ -188,12 +189,15 @@ k_wgemm_f16(const WgParams p)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
     const uint32_t r = lane & 31u, h = lane >> 5;
+    // Ring of three chunk images: while chunk c is multiplied the requests of chunks c + 1 and c + 2 are in flight (two images = 51 KB per workgroup at
+    // ef_construction 200, two workgroups per CU), and one barrier per chunk suffices: a wave that passes barrier(c) has finished chunk c - 1, whose image is
+    // the one the requests of chunk c + 2 overwrite.
     dma(0u);
+    if (nchunks > 1u) dma(1u);
     for (uint32_t c = 0; c < nchunks; c++) {
+        // chunk c has landed for this wave when at most the my_grps requests of chunk c + 1 are outstanding (zero-filling lanes issue LDS stores instead of
+        // requests in the last chunk; the count is an upper bound then, which only makes the wait stricter)
         if (c + 1u < nchunks) {
-            dma(c + 1u);
-            // wait for chunk c only: the my_grps requests of chunk c + 1 stay in flight (zero-filling lanes issue LDS stores instead; the count is an
-            // upper bound then, which only makes the wait stricter)
             switch (my_grps) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -203,8 +207,9 @@ k_wgemm_f16(const WgParams p)
             }
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                           // every wave's share of chunk c has landed
-        const lds_u8 *stage = (const lds_u8 *)(lds + (c & 1u) * (WG_NR * WG_KC));
+        __syncthreads();                                           // every wave's share of chunk c has landed, and every wave is done with chunk c - 1
+        if (c + 2u < nchunks) dma(c + 2u);
+        const lds_u8 *stage = (const lds_u8 *)(lds + (c % 3u) * p.stage_bytes);
 #pragma unroll
         for (uint32_t ks = 0; ks < WG_KC / 32u; ks++) {            // four k-steps of 16 halves: lane half h owns piece 2 ks + h
             const uint32_t kp = 2u * ks + h;
@@ -219,7 +224,6 @@ k_wgemm_f16(const WgParams p)
                 }
             }
         }
-        __syncthreads();                                           // stage c & 1 may be overwritten (by the requests of chunk c + 2)
     }
     // C/D layout of the 32x32 forms: column = lane & 31 (B row = j), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (A row = i)
     float *G = p.G + (size_t)pr * p.g_stride;
@@ -366,14 +370,15 @@ int hx_engine::mfma_select(uint32_t n_prob, uint32_t ef, const void *d_wl, const
     }
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        HX_HIP(this, hipFuncSetAttribute((const void *)k_wgemm_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_NR * WG_KC));
+        HX_HIP(this, hipFuncSetAttribute((const void *)k_wgemm_f16, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WG_NR * WG_KC + 32 * WG_KC));
         HX_HIP(this, hipFuncSetAttribute((const void *)k_wselect<OpF16<K_IP>>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         attr_set = true;
     }
     WgParams g; g.rows = d_rows; g.pitch = (uint32_t)pitch; g.ef = ef; g.m = mirror.m; g.wl = (const uint2 *)d_wl; g.wl_cnt = d_wl_cnt; g.prob_layer = d_prob_layer;
-    g.n_prob = n_prob; g.G = d_wg; g.g_stride = g_stride;
+    g.n_prob = n_prob; g.G = d_wg; g.g_stride = g_stride; g.stage_bytes = ((ef + 7u) & ~7u) * WG_KC;
+    const size_t lds_gemm = 3 * (size_t)g.stage_bytes + 31 * WG_KC;        // ef_construction 200: 80 768 B -> two workgroups per CU
     if (timing) HX_HIP(this, hipEventRecord(ev4, stream));
-    hipLaunchKernelGGL(k_wgemm_f16, dim3(n_prob), dim3(512), 2 * WG_NR * WG_KC, stream, g);
+    hipLaunchKernelGGL(k_wgemm_f16, dim3(n_prob), dim3(512), lds_gemm, stream, g);
     HX_HIP(this, hipGetLastError());
     if (timing) HX_HIP(this, hipEventRecord(ev5, stream));
     WsParams w; w.rows = d_rows; w.pitch = (uint32_t)pitch; w.nch = (uint32_t)((pitch + 1023) / 1024); w.ef = ef; w.m = mirror.m; w.wl = (const uint2 *)d_wl; w.wl_cnt = d_wl_cnt;
@@ -384,6 +389,7 @@ int hx_engine::mfma_select(uint32_t n_prob, uint32_t ef, const void *d_wl, const
     const size_t lds_sel = (64 + 64 + 64) * 4 + 64 * 8 + (((size_t)ef + 3) & ~(size_t)3) * 4 + (size_t)w.nch * 1024;
     hipLaunchKernelGGL((k_wselect<OpF16<K_IP>>), dim3(n_prob), dim3(64), lds_sel, stream, w);
     HX_HIP(this, hipGetLastError());
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
     wg_pending = timing;
     return HX_OK;
 }
@@ -414,5 +420,7 @@ int hx_engine::mfma_select_done(uint64_t gemm_pairs)
     wg_pending = false;
     float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev4, ev5));
     stat_mfma.launches++; stat_mfma.ms += ms; stat_mfma.units += gemm_pairs;
+    HX_HIP(this, hipEventElapsedTime(&ms, ev5, ev3));
+    stat_wsel.launches++; stat_wsel.ms += ms; stat_wsel.units += gemm_pairs;
     return HX_OK;
 }

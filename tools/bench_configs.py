@@ -115,11 +115,14 @@ def run(name, n, data="baseline"):
     levels = hx.draw_levels(n, m, seed=21)
     ix = hx.Index(eng, m, efc)
     eng.set_timing(True)
+    mfma_build = name == "c4" and os.environ.get("HX_MFMA", "1") != "0"     # configs[3]: select_neighbors of the build on the matrix cores (HX_MFMA=0: VALU select inside k_fused)
+    if name == "c4":
+        ix.set_mfma(mfma_build)                                             # (on by default for halfvec inner product)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ix.insert(0, levels, batch=batch)
     build = time.perf_counter() - t0
-    bstats = {"fused_insert": eng.kernel_stats(2, reset=True), "links": eng.kernel_stats(3, reset=True)}
+    bstats = {"fused_insert": eng.kernel_stats(2, reset=True), "links": eng.kernel_stats(3, reset=True), "gemm": eng.kernel_stats(4, reset=True), "wsel": eng.kernel_stats(6, reset=True)}
     eng.set_queries_device(qs.data_ptr(), nq, normalize=normalize)
     ix.search(nq, efs, k)
     eng.kernel_stats(2, reset=True)
@@ -139,6 +142,16 @@ def run(name, n, data="baseline"):
            "k_fused_insert_ms": round(bstats["fused_insert"]["ms"], 1), "k_links_ms": round(bstats["links"]["ms"], 1),
            "fused": ix.fused_stats(), "host_profile": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ix.profile().items()}}
     if name == "c4":
+        gm = bstats["gemm"]
+        if mfma_build and gm["launches"]:
+            # the build's select_neighbors ran as k_fused MODE 3 -> k_wgemm_f16 -> k_wselect: units = candidate pairs of the lower triangles, 2 * dim flops each
+            tf = gm["units"] * 2.0 * dim / max(gm["ms"], 1e-9) / 1e9
+            st = ix.mfma_stats()
+            out["build_select_gemm"] = {"kernel": "k_wgemm_f16 (v_mfma_f32_32x32x16_f16, LDS-staged W x W per member)", "launches": gm["launches"], "pairs": gm["units"], "ms": round(gm["ms"], 1),
+                                        "TFLOPs": round(tf, 1), "mfma_util_vs_2.5PF_dense_f16": round(tf / 2500.0, 4),
+                                        "rows_streamed_GBps": round(gm["units"] / (efc * (efc - 1) / 2.0) * efc * row_bytes / max(gm["ms"], 1e-9) / 1e6, 1),
+                                        "k_wselect_ms": round(bstats["wsel"]["ms"], 1), "decisions_from_matrix": st["mfma_pairs"], "pairs_re_evaluated_canonically": st["exact_pairs"]}
+        out["build_select_on_matrix_cores"] = bool(mfma_build)
         # configs[3]: "fp16 MFMA batched-build distance GEMM".  The operands of select_neighbors are blocks of <= 64 rows that lie close together in the
         # graph: an element, its layer-0 neighbours and theirs.  k_pair_mfma_f16 (matrix cores) against k_pair_groups (exact VALU order) on such blocks
         # of THIS index; utilisation against the 2.5 PFLOP/s dense f16 peak (MI355X_MICROARCH.md).

@@ -19,19 +19,29 @@ def main():
             name = r.get("Name", "")[:60]
             print("%-60s %10s %14s %12s %8s" % (name, r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
     for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
-        agg = defaultdict(lambda: [0, 0, 0, 0, 0])
+        agg = defaultdict(lambda: [0, 0, 0, 0, 0, 0, 0, 0])
+
+        def num(r, *names):
+            for nm in names:
+                v = r.get(nm)
+                if v not in (None, ""):
+                    return int(float(v))
+            return 0
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"][:60]
             a = agg[k]
             a[0] += 1
             a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-            a[2] = max(a[2], int(r.get("VGPR_Count", 0) or 0))
-            a[3] = max(a[3], int(r.get("LDS_Block_Size", 0) or 0))
-            a[4] = max(a[4], int(r.get("Workgroup_Size", 0) or r.get("Workgroup_Size_X", 0) or 0))
+            a[2] = max(a[2], num(r, "VGPR_Count", "Arch_VGPR_Count"))           # the ALLOCATION granule (multiples of 8), not the compiler's count: tools/kres.py prints that
+            a[3] = max(a[3], num(r, "LDS_Block_Size"))
+            a[4] = max(a[4], num(r, "Workgroup_Size", "Workgroup_Size_X"))
+            a[5] = max(a[5], num(r, "Accum_VGPR_Count"))
+            a[6] = max(a[6], num(r, "SGPR_Count"))
+            a[7] = max(a[7], num(r, "Scratch_Size", "Private_Segment_Size", "Scratch_Memory_Size"))
         print("\n## kernel trace aggregate (%s)" % os.path.basename(f))
-        print("%-60s %10s %14s %12s %6s %8s %6s" % ("kernel", "calls", "total_ns", "avg_ns", "vgpr", "lds", "wg"))
-        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]:
-            print("%-60s %10d %14d %12.1f %6d %8d %6d" % (k, a[0], a[1], a[1] / a[0], a[2], a[3], a[4]))
+        print("%-60s %10s %14s %12s %9s %10s %5s %8s %8s %6s" % ("kernel", "calls", "total_ns", "avg_ns", "arch_vgpr", "accum_vgpr", "sgpr", "scratch", "lds", "wg"))
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+            print("%-60s %10d %14d %12.1f %9d %10d %5d %8d %8d %6d" % (k, a[0], a[1], a[1] / a[0], a[2], a[5], a[6], a[7], a[3], a[4]))
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
         for r in csv.DictReader(open(f)):
