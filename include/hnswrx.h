@@ -221,6 +221,12 @@ int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_recor
 int hx_index_dbatch_links(hx_index *ix, uint32_t rank, uint32_t world, const void *d_records, uint64_t *n_list_records);
 int hx_index_dbatch_export_links(hx_index *ix, void *d_out);
 int hx_index_dbatch_import_links(hx_index *ix, const void *d_list_records, uint64_t n);
+/* Optional exchange between _search and _links: the W tables of members [lo, hi) (hx_index_dbatch_wtab_bytes per member; 0 = tables off) as written by
+ * the rank that searched them -> d_out, and another rank's -> the engine.  With them a rank prunes the lists it owns with the look-ups a single GPU has
+ * instead of streaming the rows again; results do not depend on it (a look-up returns the very bits a recomputation gives). */
+uint64_t hx_index_dbatch_wtab_bytes(const hx_index *ix);
+int hx_index_dbatch_export_wtabs(hx_index *ix, uint32_t lo, uint32_t hi, void *d_out);
+int hx_index_dbatch_import_wtabs(hx_index *ix, uint32_t lo, uint32_t hi, const void *d_in);
 int hx_index_dbatch_end(hx_index *ix, uint32_t *elem_out);
 
 /* ---- f3: the on-disk paths on the engine ---------------------------------------------------------

@@ -107,6 +107,9 @@ extern "C" {
     pub fn hx_index_dbatch_links(ix: *mut hx_index, rank: u32, world: u32, d_records: *const c_void, n_list_records: *mut u64) -> c_int;
     pub fn hx_index_dbatch_export_links(ix: *mut hx_index, d_out: *mut c_void) -> c_int;
     pub fn hx_index_dbatch_import_links(ix: *mut hx_index, d_list_records: *const c_void, n: u64) -> c_int;
+    pub fn hx_index_dbatch_wtab_bytes(ix: *const hx_index) -> u64;
+    pub fn hx_index_dbatch_export_wtabs(ix: *mut hx_index, lo: u32, hi: u32, d_out: *mut c_void) -> c_int;
+    pub fn hx_index_dbatch_import_wtabs(ix: *mut hx_index, lo: u32, hi: u32, d_in: *const c_void) -> c_int;
     pub fn hx_index_dbatch_end(ix: *mut hx_index, elem_out: *mut u32) -> c_int;
     // graph export / import
     pub fn hx_index_size(ix: *const hx_index) -> u32;

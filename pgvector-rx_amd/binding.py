@@ -107,6 +107,9 @@ def lib():
         "hx_index_dbatch_links": (i32, [vp, u32, u32, vp, C.POINTER(u64)]),
         "hx_index_dbatch_export_links": (i32, [vp, vp]),
         "hx_index_dbatch_import_links": (i32, [vp, vp, u64]),
+        "hx_index_dbatch_wtab_bytes": (u64, [vp]),
+        "hx_index_dbatch_export_wtabs": (i32, [vp, u32, u32, vp]),
+        "hx_index_dbatch_import_wtabs": (i32, [vp, u32, u32, vp]),
         "hx_index_dbatch_end": (i32, [vp, vp]),
         "hx_index_size": (u32, [vp]),
         "hx_index_entry": (i64, [vp]),
@@ -414,6 +417,17 @@ class Index:
 
     def dbatch_import_links(self, d_list_records, n):
         self._ck(lib().hx_index_dbatch_import_links(self.h, C.c_void_p(d_list_records), n))
+
+    @property
+    def dbatch_wtab_bytes(self):
+        """Bytes per member of the W-table exchange of the open device batch (0: tables off)."""
+        return lib().hx_index_dbatch_wtab_bytes(self.h)
+
+    def dbatch_export_wtabs(self, lo, hi, d_out):
+        self._ck(lib().hx_index_dbatch_export_wtabs(self.h, lo, hi, C.c_void_p(d_out)))
+
+    def dbatch_import_wtabs(self, lo, hi, d_in):
+        self._ck(lib().hx_index_dbatch_import_wtabs(self.h, lo, hi, C.c_void_p(d_in)))
 
     def dbatch_end(self, n):
         out = np.empty(n, np.uint32)

@@ -1660,6 +1660,39 @@ int hx_index_dbatch_import_links(hx_index *ix, const void *d_list_records, uint6
     return HX_OK;
 }
 
+// The members' W tables (d(new row, x) for every x the member's layer-0 search kept: what the back-link kernels look up instead of streaming row x)
+// exist only on the rank that searched the member.  Exchange format, per member: the table (wt_size x {distance bits, id}) + 16 bytes whose first is
+// the valid flag.  A rank that imports the other ranks' tables prunes its own lists with the same look-ups a single GPU has.
+uint64_t hx_index_dbatch_wtab_bytes(const hx_index *ix)
+{
+    if (!ix || !ix->bs.open || !ix->bs.dev || ix->e->bw.wt_size == 0) return 0;
+    return (uint64_t)ix->e->bw.wt_size * 8 + 16;
+}
+
+static int wtab_copy(hx_index *ix, uint32_t lo, uint32_t hi, void *d_buf, bool out)
+{
+    if (!ix || !ix->bs.open || !ix->bs.dev) return HX_E_ARG;
+    hx_engine *e = ix->e;
+    if (hi < lo || hi > ix->bs.b) return ix->fail(HX_E_ARG, "bad member range");
+    if (hi == lo || e->bw.wt_size == 0) return HX_OK;
+    if (!d_buf) return ix->fail(HX_E_ARG, "buffer is NULL");
+    const size_t tb = (size_t)e->bw.wt_size * 8, stride = tb + 16, n = hi - lo;
+    uint8_t *tab = (uint8_t *)e->bw.d_wtab + (size_t)lo * tb, *val = e->bw.d_wt_valid + lo, *buf = (uint8_t *)d_buf;
+    hipError_t s;
+    if (out) {
+        s = hipMemcpy2DAsync(buf, stride, tab, tb, tb, n, hipMemcpyDeviceToDevice, e->stream);
+        if (s == hipSuccess) s = hipMemcpy2DAsync(buf + tb, stride, val, 1, 1, n, hipMemcpyDeviceToDevice, e->stream);
+    } else {
+        s = hipMemcpy2DAsync(tab, tb, buf, stride, tb, n, hipMemcpyDeviceToDevice, e->stream);
+        if (s == hipSuccess) s = hipMemcpy2DAsync(val, 1, buf + tb, stride, 1, n, hipMemcpyDeviceToDevice, e->stream);
+    }
+    if (s == hipSuccess && out) s = hipStreamSynchronize(e->stream);      // the caller hands the buffer to a collective on another stream
+    if (s != hipSuccess) return ix->fail(HX_E_HIP, std::string("W table exchange: ") + hipGetErrorString(s));
+    return HX_OK;
+}
+int hx_index_dbatch_export_wtabs(hx_index *ix, uint32_t lo, uint32_t hi, void *d_out) { return wtab_copy(ix, lo, hi, d_out, true); }
+int hx_index_dbatch_import_wtabs(hx_index *ix, uint32_t lo, uint32_t hi, const void *d_in) { return wtab_copy(ix, lo, hi, (void *)d_in, false); }
+
 int hx_index_dbatch_end(hx_index *ix, uint32_t *elem_out)
 {
     if (!ix) return HX_E_ARG;

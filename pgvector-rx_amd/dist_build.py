@@ -25,7 +25,10 @@ import time
 import numpy as np
 import torch
 
+import os
+
 STAGE_SECONDS = {}      # wall time per stage of the last insert_sharded call (rank-local, for bench.py's report)
+WTAB_EXCHANGE = os.environ.get("HX_DIST_WTABS", "1") != "0"
 
 
 class Comm:
@@ -166,6 +169,20 @@ def _device_batch(ix, first_row, levels, tids, dist, device, gpu, world, rank):
     t0 = _t("search", t0)
     recs = all_gather_device(send, world, dist, device)
     t0 = _t("allgather_new", t0)
+    # the members' W tables travel too (4 KB each at ef_construction 200): every rank then prunes the lists it owns with the look-ups a single GPU
+    # has for ALL members instead of streaming the rows of the members other ranks searched (HX_DIST_WTABS=0: off)
+    wb = getattr(ix, "dbatch_wtab_bytes", 0) if WTAB_EXCHANGE and world > 1 else 0
+    if wb:
+        wsend = torch.zeros(per * wb, dtype=torch.uint8, device=gpu)
+        if on_gpu:
+            torch.cuda.current_stream(gpu).synchronize()
+        ix.dbatch_export_wtabs(lo, hi, wsend.data_ptr())
+        wrecv = all_gather_device(wsend, world, dist, device)
+        for r in range(world):
+            rlo, rhi = min(b, r * per), min(b, r * per + per)
+            if r != rank and rhi > rlo:
+                ix.dbatch_import_wtabs(rlo, rhi, wrecv.data_ptr() + r * per * wb)
+        t0 = _t("allgather_wtabs", t0)
     mine = ix.dbatch_links(rank, world, recs.data_ptr())
     t0 = _t("links", t0)
     sizes = gather_sizes(mine, dist, device)

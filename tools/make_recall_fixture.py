@@ -4,7 +4,7 @@ build_callback, ORC_ORDER_SEQ, one row at a time) on 100 000 x vector(768) L2, m
 shape and data distribution at a size one CPU core finishes in under an hour.  tests/test_gpu_recall_parity.py rebuilds the same rows
 with the batched device build (batch cap 8192) and demands the same recall within sampling noise.
 
-Run once on a CPU box:  python tools/make_recall_fixture.py [rows]     (100 000 rows: 10 min of one core, 300 000: ~40 min; commit the JSON it writes)"""
+Run once on a CPU box:  python tools/make_recall_fixture.py [rows [centres]]     (100 000 rows: 10 min of one core, 300 000: ~40 min, 1 000 000 x 1024 centres: hours; commit the JSON it writes)"""
 import json
 import os
 import sys
@@ -48,6 +48,8 @@ def main():
     cfg = dict(CFG)
     if len(sys.argv) > 1:                                      # python tools/make_recall_fixture.py 300000 -> tests/golden/recall_parity_300k.json
         cfg["rows"] = int(sys.argv[1])
+    if len(sys.argv) > 2:                                      # python tools/make_recall_fixture.py 1000000 1024 -> the bench's own size and mixture (1024 centres)
+        cfg["centres"] = int(sys.argv[2])
     rows, qs = make_data(cfg)
     levels = hx.draw_levels(cfg["rows"], cfg["m"], seed=cfg["seed_levels"])
     o = orc.Index(orc.F32, orc.L2SQ, cfg["dim"], m=cfg["m"], ef_construction=cfg["ef_construction"], order=orc.SEQ)
