@@ -516,7 +516,7 @@ def test_full_size_c2_structural_properties():
     e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
     e.append_device(rows.data_ptr(), n)
     ix = hx.Index(e, m, efc)
-    ix.insert(0, levels, batch=8192)
+    ix.insert(0, levels, batch=32768)                                   # the bench's insert batch cap (bench.py --batch)
     assert ix.size == n and ix.fused_stats()["redone"] == 0
     lv = ix.export_levels()
     assert np.array_equal(lv, levels)                                   # no duplicates in this data: nothing tombstoned

@@ -67,8 +67,8 @@ for b in hx.batch_schedule(0, n, cap):
     done += b
 for k, v in T.items():
     print(k, [round(x, 3) for x in v])
+for r, (e, ix) in enumerate(ranks):
+    print("rank", r, "fused", e.kernel_stats(2), "links", e.kernel_stats(3), {k: round(v, 3) for k, v in ix.profile().items() if v})
 print(json.dumps({"rows": n, "world": world, "wtabs_exchanged": bool(wtabs and world > 1), "batch_cap": cap,
                   "stage_seconds_max_over_ranks": {k: round(max(v), 3) for k, v in T.items()},
                   "kernel_ms_rank0": {"fused_insert": round(ranks[0][0].kernel_stats(2)["ms"], 1), "links": round(ranks[0][0].kernel_stats(3)["ms"], 1)}}))
-for r, (e, ix) in enumerate(ranks):
-    print("rank", r, "fused", e.kernel_stats(2), "links", e.kernel_stats(3), {k: round(v, 3) for k, v in ix.profile().items() if v})
