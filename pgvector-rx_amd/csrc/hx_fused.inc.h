@@ -313,7 +313,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     p.status = (uint32_t *)(io.d_io + o_st);
     p.o_cst = FUSED_MAXL; p.o_lst = FUSED_MAXL * 2 * mr.m; p.t_oslot = nullptr;
     p.wtab = nullptr; p.wt_size = 0; p.wt_slot0 = 0; p.wt_valid = nullptr;
-    p.wl_out = nullptr; p.wl_cnt = nullptr; p.t_prob = nullptr;
+    p.wl_out = nullptr; p.wl_cnt = nullptr; p.t_prob = nullptr; p.ondisk = (mode == 3 && dev && dev->ondisk) ? 1u : 0u;
     if (mode == 3) { p.wl_out = (uint2 *)dev->d_wl_out; p.wl_cnt = dev->d_wl_cnt; p.t_prob = (const uint32_t *)(io.d_io + o_prob); }
     if (dev && dev->d_wtab) { p.wtab = (uint2 *)dev->d_wtab; p.wt_size = dev->wt_size; p.wt_slot0 = dev->wt_slot0; p.wt_valid = dev->d_wt_valid; }
     if (dev) {   // record = cnt[FUSED_MAXL] | ids[FUSED_MAXL][2m] | d[FUSED_MAXL][2m]  (hx_batch.hip reads the same layout)

@@ -56,6 +56,7 @@ struct FusedParams {
     // MODE 3 (insert, search only: select_neighbors runs on the matrix cores afterwards, hx_mfma.hip): the sorted result set W of layer lc of task t goes to
     // problem t_prob[t] + lc: wl_out[problem * ef + i] = {distance bits, id}, wl_cnt[problem] = |W|
     uint2 *wl_out; uint32_t *wl_cnt; const uint32_t *t_prob;
+    uint32_t ondisk;                              // MODE 3 for aminsert: search_layer_disk semantics (W handed out nearest LAST, as scan.rs:441-446 sorts it)
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
     // iterative scan (k_fused MODE 2): hnsw.iterative_scan relaxed_order (1) / strict_order (2), scan.rs:794-875
     uint32_t iter_mode, limit; long long max_tuples;

@@ -492,6 +492,9 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
 
         // greedy descent with ef = 1: mod.rs:385-399 (down to new_level+1) / scan.rs:491-512 (down to 1)
         const int stop_above = INS ? new_level : 0;
+        // search_layer_disk's semantics (f64 comparisons, results nearest LAST, that order as the next layer's entry points): scans, and MODE 3 when it
+        // serves aminsert's find_element_neighbors_on_disk (insert.rs:1021-1123; p.ondisk) instead of the build's find_element_neighbors
+        const bool scan_sem = !INS || (MODE == 3 && p.ondisk != 0u);
         for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
 #ifdef HX_EXPERIMENTS
             if constexpr (SA) {
@@ -501,13 +504,13 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
                 continue;
             }
 #endif
-            f_search_layer<OP, LPR, false>(p, cx, n_ep, 1u, lc, !INS);
+            f_search_layer<OP, LPR, false>(p, cx, n_ep, 1u, lc, scan_sem);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
-                f_sort_results(cx, wl, !INS);
-                if (!INS) { const uint2 best = cx.EP[wl - 1]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); }
+                f_sort_results(cx, wl, scan_sem);
+                if (scan_sem) { const uint2 best = cx.EP[wl - 1]; F_BAR(); if (lane == 0) cx.EP[0] = best; F_BAR(); }   // w.into_iter().last(): scan.rs:506-510 / insert.rs:1069-1073
                 n_ep = 1;                         // MODE 1: ep = vec![w[0]]; EP[0] already is the nearest
-            } else if (!INS) { n_ep = 0; break; }
+            } else if (scan_sem) { n_ep = 0; break; }
         }
 
         if (MODE == 2) {
@@ -597,12 +600,12 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
             for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
             KParams &p_task = p;
             for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
-                f_search_layer<OP, LPR, false>(p_task, cx, n_ep, p_task.ef, lc, false);      // mod.rs:407-416
+                f_search_layer<OP, LPR, false>(p_task, cx, n_ep, p_task.ef, lc, scan_sem);   // mod.rs:407-416 / insert.rs:1088-1101
                 if (cx.status != FS_OK) break;
                 KParams &p = f_params_here(p_task);            // the select phase derives its own view of the parameters (dead again when the layer is done)
                 const uint32_t lm = lc == 0 ? lm0 : p.m;
                 const uint32_t wl = cx.CTL[1];
-                f_sort_results(cx, wl, false);                                       // W ascending; also the next layer's entry points (mod.rs:425)
+                f_sort_results(cx, wl, scan_sem);                                    // W ascending (build; on-disk: nearest last); also the next layer's entry points (mod.rs:425, insert.rs:1119)
                 n_ep = wl;
                 if (lc == 0 && p.wtab) {
                     // W (ids + distance bits) as a hash table for the back-link kernels: built in the candidate heap's LDS (dead until the
@@ -733,8 +736,7 @@ static hipError_t launch_fused_lpr(hx_engine *e, const FusedParams &p, uint32_t 
 #ifdef HX_EXPERIMENTS
     if constexpr (OP::sorted_array_ok) { if (p.sa && mode == 0) return launch_fused<OP, 0, LPR, true>(e, p, grid, lds); }
 #endif
-    if constexpr (OP::mfma_split_ok && LPR == 64) { if (mode == 3) return launch_fused<OP, 3, LPR>(e, p, grid, lds); }
-    if (mode == 3) return hipErrorInvalidValue;          // the host only asks for it where it is built (halfvec inner product, rows > 512 B)
+    if (mode == 3) return launch_fused<OP, 3, LPR>(e, p, grid, lds);      // search only: the matrix-core select (hx_mfma.hip) and aminsert's nearest-lm (insert.rs:1111-1117) take the W lists
     return mode == 0 ? launch_fused<OP, 0, LPR>(e, p, grid, lds) : launch_fused<OP, 1, LPR>(e, p, grid, lds);
 }
 template <class OP>

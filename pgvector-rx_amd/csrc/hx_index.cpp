@@ -1788,6 +1788,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     int rc = ix->ensure_host_lists();
     if (rc) return rc;
     const int mxl = max_level_for(g.m);
+    const bool any_deleted = std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) != g.deleted.end();
     uint32_t done = 0;
     while (done < n) {
         if (g.entry < 0) {                                                          // first element: insert.rs:1320-1338 (no entry point yet)
@@ -1801,33 +1802,81 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
         const uint32_t b = std::min(batch, n - done), base = g.size();
         const uint32_t entry = (uint32_t)g.entry; const int entry_level = g.level[entry];
         // stage 1: every member's neighbour search against the graph as it stands (batch == 1: the reference's one insert at a time;
-        // batch > 1: what concurrent backends do -- each searches without seeing the others' uncommitted elements, e.g. 013's 10 pgbench clients)
-        auto &dts = ix->disk_pool;
-        while (dts.size() < b) dts.emplace_back(new DiskNeighborsTask());
-        std::vector<LsTask *> tasks(b);
-        for (uint32_t i = 0; i < b; i++) {
-            DiskNeighborsTask &t = *dts[i];
-            t.reset();
-            int lv = std::min(levels[done + i], mxl); if (lv < 0) lv = 0;
-            t.g = &g; t.query_sel = base + i; t.new_level = lv; t.entry = entry; t.entry_level = entry_level; t.efc = ix->efc;
-            t.skip = nullptr; t.skip_self = 0xFFFFFFFFu; t.repair = false;
-            tasks[i] = &t;
+        // batch > 1: what concurrent backends do -- each searches without seeing the others' uncommitted elements, e.g. 013's 10 pgbench clients).
+        // Device-resident placement: find_element_neighbors_on_disk (insert.rs:1021-1123) is the traversal kernel's MODE 3 -- the greedy descent and a
+        // search_layer per layer, the sorted result set W of every layer handed out -- and its "filtered.iter().rev().take(lm)" (:1111-1117) the first lm
+        // entries of W.  (An index that holds deleted elements -- between VACUUM's passes they are skipped by load_element, scan.rs:178-181 -- and what the
+        // kernel does not serve go through the lock-step driver, as does every member whose tables overflow.)
+        std::vector<std::vector<std::vector<Cand>>> nbs(b);                          // [member][layer]: nearest first
+        std::vector<int> mlv(b);
+        for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[done + i], mxl); if (lv < 0) lv = 0; mlv[i] = lv; nbs[i].assign(lv + 1, {}); }
+        std::vector<uint32_t> ls_members;                                            // members for the lock-step driver
+        if (ix->fused_ok() && !any_deleted && b >= 1) {
+            if ((rc = ix->sync_mirror())) return rc;
+            hx_engine *e = ix->e;
+            std::vector<uint32_t> qsel(b), prob(b), tstat(b); std::vector<int32_t> tl(b);
+            uint32_t P = 0;
+            for (uint32_t i = 0; i < b; i++) { qsel[i] = base + i; tl[i] = mlv[i]; prob[i] = P; P += (uint32_t)std::min(mlv[i], entry_level) + 1u; }
+            if ((rc = e->wsel_reserve(P, (uint32_t)ix->efc)) || (rc = e->db_reserve_records(b))) return ix->fail(rc, e->err);
+            HxWselWork &w = e->wsel;
+            if (hipMemsetAsync(w.d_cnt, 0, (size_t)P * 4, e->stream) != hipSuccess) return ix->fail(HX_E_HIP, "on-disk insert: clearing the W counts failed");
+            HxFusedDev dev; dev.d_rec = e->bw.d_rec; dev.rec_words = hx_rec_words((uint32_t)g.m); dev.h_slots = nullptr;
+            dev.d_wl_out = w.d_wl; dev.d_wl_cnt = w.d_cnt; dev.h_prob = prob.data(); dev.ondisk = true;
+            uint64_t cnts[2] = {0, 0};
+            const double t0 = hx_index::now_s();
+            if ((rc = e->fused_run(3, b, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, entry, entry_level,
+                                   nullptr, nullptr, nullptr, tstat.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, e->err);
+            ix->prof[6] += hx_index::now_s() - t0;
+            ix->counters[4] += cnts[0];
+            std::vector<uint32_t> wcnt(P); std::vector<uint2> wl((size_t)P * ix->efc);
+            if (hipMemcpyAsync(wcnt.data(), w.d_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+                hipMemcpyAsync(wl.data(), w.d_wl, (size_t)P * ix->efc * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+                hipStreamSynchronize(e->stream) != hipSuccess) return ix->fail(HX_E_HIP, "on-disk insert: reading the W lists failed");
+            for (uint32_t i = 0; i < b; i++) {
+                if (tstat[i] != 0) { ls_members.push_back(i); continue; }
+                const int start = std::min(mlv[i], entry_level);
+                for (int lc = 0; lc <= start; lc++) {
+                    const size_t pr = (size_t)prob[i] + (size_t)lc, lm = (size_t)g.lm(lc);
+                    const uint2 *W = wl.data() + pr * ix->efc;                       // nearest LAST (scan.rs:441-446)
+                    std::vector<Cand> &out = nbs[i][lc];
+                    for (size_t k = wcnt[pr]; k-- > 0 && out.size() < lm;) { Cand c; memcpy(&c.d, &W[k].x, 4); c.id = W[k].y; out.push_back(c); }   // filtered.iter().rev().take(lm), insert.rs:1111-1117
+                }
+            }
+            ix->fused_tasks += b; ix->fused_redo += ls_members.size();
+        } else {
+            for (uint32_t i = 0; i < b; i++) ls_members.push_back(i);
         }
-        if ((rc = ix->run_lockstep(tasks))) return rc;
+        if (!ls_members.empty()) {
+            auto &dts = ix->disk_pool;
+            while (dts.size() < ls_members.size()) dts.emplace_back(new DiskNeighborsTask());
+            std::vector<LsTask *> tasks(ls_members.size());
+            for (size_t k = 0; k < ls_members.size(); k++) {
+                DiskNeighborsTask &t = *dts[k];
+                t.reset();
+                t.g = &g; t.query_sel = base + ls_members[k]; t.new_level = mlv[ls_members[k]]; t.entry = entry; t.entry_level = entry_level; t.efc = ix->efc;
+                t.skip = nullptr; t.skip_self = 0xFFFFFFFFu; t.repair = false;
+                tasks[k] = &t;
+            }
+            if ((rc = ix->run_lockstep(tasks))) return rc;
+            for (size_t k = 0; k < ls_members.size(); k++) {
+                DiskNeighborsTask &t = *dts[k];
+                ix->counters[4] += t.n_dist;
+                for (int lc = 0; lc <= t.new_level && lc < (int)t.nb.size(); lc++) nbs[ls_members[k]][lc] = t.nb[lc];
+            }
+        }
         // duplicate candidates: leading zero-distance layer-0 neighbours, compared byte for byte (find_duplicate_on_disk insert.rs:1180-1214)
         std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0u);
         for (uint32_t i = 0; i < b; i++) {
-            const DiskNeighborsTask &t = *dts[i];
-            if (!t.nb.empty()) for (const Cand &c : t.nb[0]) { if (c.d != 0.0f) break; da.push_back(base + i); db.push_back(c.id); }
+            if (!nbs[i].empty()) for (const Cand &c : nbs[i][0]) { if (c.d != 0.0f) break; da.push_back(base + i); db.push_back(c.id); }
             dstart[i + 1] = (uint32_t)da.size();
         }
         std::vector<uint8_t> deq(da.size(), 0);
         if (!da.empty() && (rc = hx_rows_equal(ix->e, (uint32_t)da.size(), da.data(), db.data(), deq.data()))) return ix->fail(rc, ix->e->err);
-        // stage 2: members in order -- duplicate merge, or element + back-connections
+        // stage 2a: members in order -- duplicate merge, or the element, its own lists, the entry point; its back-connections are listed
+        struct UOp { uint32_t nbr; int layer; uint32_t id; float d; };
+        std::vector<UOp> ops;
         for (uint32_t i = 0; i < b; i++) {
-            DiskNeighborsTask &t = *dts[i];
-            ix->counters[4] += t.n_dist;
-            const uint32_t id = g.add(t.new_level);                                 // element id == row id, also for a merged row (tombstone)
+            const uint32_t id = g.add(mlv[i]);                                      // element id == row id, also for a merged row (tombstone)
             int64_t dup = -1;
             for (uint32_t k = dstart[i]; k < dstart[i + 1]; k++)
                 if (deq[k] && g.ntids[db[k]] > 0 && g.ntids[db[k]] < HEAPTIDS && !g.deleted[db[k]]) { dup = db[k]; break; }   // add_duplicate_on_disk :1136-1171
@@ -1837,34 +1886,55 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
                 if (elem_out) elem_out[done + i] = (uint32_t)dup;
                 continue;
             }
-            for (int lc = 0; lc <= t.new_level; lc++) {                             // the new element's neighbour tuple, insert.rs:1384-1410
-                Cand *lst = g.list(id, lc); const size_t c = std::min(t.nb[lc].size(), (size_t)g.lm(lc));
-                for (size_t k = 0; k < c; k++) lst[k] = t.nb[lc][k];
+            for (int lc = 0; lc <= mlv[i]; lc++) {                                  // the new element's neighbour tuple, insert.rs:1384-1410
+                Cand *lst = g.list(id, lc); const size_t c = std::min(nbs[i][lc].size(), (size_t)g.lm(lc));
+                for (size_t k = 0; k < c; k++) lst[k] = nbs[i][lc][k];
                 g.cnt(id, lc) = (uint16_t)c;
             }
             g.tids[id][0] = tids[done + i]; g.ntids[id] = 1;
             ix->mark_dirty(id);
-            // update_neighbors_on_disk insert.rs:883-958: one get_update_index per (neighbour, layer); distinct lists, so they run in lock-step
-            auto &uts = ix->update_pool; std::vector<LsTask *> utasks;
-            size_t nu = 0;
-            for (int lc = t.new_level; lc >= 0; lc--) {
+            for (int lc = mlv[i]; lc >= 0; lc--) {                                  // update_neighbors_on_disk insert.rs:883-958: one get_update_index per (neighbour, layer)
                 const size_t lm = (size_t)g.lm(lc);
-                for (size_t k = 0; k < t.nb[lc].size() && k < lm; k++) {
-                    if (nu == uts.size()) uts.emplace_back(new UpdateIndexTask());
-                    UpdateIndexTask &u = *uts[nu++];
-                    u.reset(); u.g = &g; u.nbr = t.nb[lc][k].id; u.layer = lc; u.new_d = t.nb[lc][k].d;
-                    utasks.push_back(&u);
+                for (size_t k = 0; k < nbs[i][lc].size() && k < lm; k++) ops.push_back(UOp{nbs[i][lc][k].id, lc, id, nbs[i][lc][k].d});
+            }
+            if (mlv[i] > g.level[g.entry]) g.entry = id;                            // insert.rs:1453-1470 (HNSW_UPDATE_ENTRY_GREATER)
+            if (elem_out) elem_out[done + i] = id;
+        }
+        // stage 2b: get_update_index reads and write_neighbor_update writes ONE list (and row data, deleted flags and heap-TID counts, which the
+        // back-connections do not change), so updates of different lists commute: the batch's updates run as waves -- wave k holds the k-th update of
+        // every list, in member order per list -- one lock-step round per wave instead of one per member.  batch == 1 is the reference's order exactly.
+        if (!ops.empty()) {
+            std::vector<uint32_t> order(ops.size());
+            for (uint32_t k = 0; k < ops.size(); k++) order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+                return ops[x].nbr != ops[y].nbr ? ops[x].nbr < ops[y].nbr : ops[x].layer < ops[y].layer; });
+            std::vector<std::pair<uint32_t, uint32_t>> runs;                          // [first, end) of every list's updates in `order`
+            for (uint32_t k = 0; k < order.size();) {
+                uint32_t j = k + 1;
+                while (j < order.size() && ops[order[j]].nbr == ops[order[k]].nbr && ops[order[j]].layer == ops[order[k]].layer) j++;
+                runs.emplace_back(k, j); k = j;
+            }
+            auto &uts = ix->update_pool;
+            for (uint32_t wave = 0;; wave++) {
+                std::vector<LsTask *> utasks; std::vector<uint32_t> which;
+                for (const auto &r : runs) {
+                    if (r.first + wave >= r.second) continue;
+                    const UOp &o = ops[order[r.first + wave]];
+                    if (utasks.size() == uts.size()) uts.emplace_back(new UpdateIndexTask());
+                    UpdateIndexTask &u = *uts[utasks.size()];
+                    u.reset(); u.g = &g; u.nbr = o.nbr; u.layer = o.layer; u.new_d = o.d;
+                    utasks.push_back(&u); which.push_back(order[r.first + wave]);
+                }
+                if (utasks.empty()) break;
+                if ((rc = ix->run_lockstep(utasks))) return rc;
+                for (size_t k = 0; k < utasks.size(); k++) {
+                    UpdateIndexTask &u = *uts[k];
+                    ix->counters[3] += u.n_dist + u.n_pair;
+                    if (u.result == -3) continue;
+                    const UOp &o = ops[which[k]];
+                    write_neighbor_update(ix, o.nbr, o.layer, o.id, o.d, u.result);
                 }
             }
-            if ((rc = ix->run_lockstep(utasks))) return rc;
-            for (size_t k = 0; k < nu; k++) {
-                UpdateIndexTask &u = *uts[k];
-                ix->counters[3] += u.n_dist + u.n_pair;
-                if (u.result == -3) continue;
-                write_neighbor_update(ix, u.nbr, u.layer, id, u.new_d, u.result);
-            }
-            if (t.new_level > g.level[g.entry]) g.entry = id;                       // insert.rs:1453-1470 (HNSW_UPDATE_ENTRY_GREATER)
-            if (elem_out) elem_out[done + i] = id;
         }
         done += b;
     }
