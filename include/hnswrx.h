@@ -88,7 +88,8 @@ void *hx_stream(const hx_engine *e);         /* the hipStream_t every kernel of 
 /* Appends n rows (host memory, row-major, hx_row_bytes each); *first_row_id = id of the first.
  * Mirrors bs.values.extend_from_slice, build.rs:451-454. */
 int hx_append_rows(hx_engine *e, const void *rows_host, uint64_t n, uint64_t *first_row_id);
-/* Same, rows already in device memory (synthetic benches keep data in HBM). */
+/* Same, rows already in device memory (synthetic benches keep data in HBM).  The device is synchronised first (hipDeviceSynchronize): whatever stream
+ * produced the buffer has finished before it is copied.  hx_set_queries_device does the same. */
 int hx_append_rows_device(hx_engine *e, const void *rows_dev, uint64_t n, uint64_t *first_row_id);
 /* Drops the last n rows: bs.values.truncate on a duplicate, build.rs:507-509. */
 int hx_pop_rows(hx_engine *e, uint64_t n);

@@ -515,6 +515,9 @@ static int append_impl(hx_engine *e, const void *rows, uint64_t n, uint64_t *fir
     HX_HIP(e, hipSetDevice(e->device));
     uint8_t *dst = e->d_rows + e->n_rows * e->pitch;
     if (n) {
+        // a device source was produced on a stream this library does not know (the engine's own is non-blocking): wait for the device, so that rows
+        // still being written by the caller's kernels are not copied half-done
+        if (kind == hipMemcpyDeviceToDevice) HX_HIP(e, hipDeviceSynchronize());
         if (e->pitch != e->row_bytes) HX_HIP(e, hipMemsetAsync(dst, 0, n * e->pitch, e->stream));
         HX_HIP(e, hipMemcpy2DAsync(dst, e->pitch, rows, e->row_bytes, e->row_bytes, n, kind, e->stream));
         HX_HIP(e, hipStreamSynchronize(e->stream));
@@ -583,6 +586,7 @@ static int set_queries_impl(hx_engine *e, const void *q, uint32_t nq, int normal
         HX_HIP(e, hipMalloc((void **)&e->d_queries, (size_t)(e->cap_queries + 1) * e->pitch));
     }
     if (nq) {
+        if (kind == hipMemcpyDeviceToDevice) HX_HIP(e, hipDeviceSynchronize());      // as hx_append_rows_device: the caller's producer stream is unknown
         if (e->pitch != e->row_bytes) HX_HIP(e, hipMemsetAsync(e->d_queries, 0, (size_t)nq * e->pitch, e->stream));
         HX_HIP(e, hipMemcpy2DAsync(e->d_queries, e->pitch, q, e->row_bytes, e->row_bytes, nq, kind, e->stream));
     }

@@ -271,3 +271,42 @@ def test_sparsevec_vacuum_insert_rounds_on_device():
             assert got[q, :cnt[q]].tolist() == want and not (set(want) & dead)
     ix.close()
     e.close()
+
+
+@pytest.mark.parametrize("dtype,metric,dim", [(hx.F32, hx.L2SQ, 48), (hx.BIT, hx.HAMMING, 64), (hx.F16, hx.NEG_IP, 300)])
+def test_ondisk_batches_device_search_equals_lock_step_search(dtype, metric, dim):
+    """Concurrent aminserts (batch > 1, several calls in a row): the placement that searches in the traversal kernel (MODE 3, search_layer_disk semantics)
+    and runs get_update_index in waves must leave the very graph the lock-step placement (one round per expansion, one per member) leaves."""
+    rng = np.random.default_rng(dim)
+    n0, m, efc = 3000, 12, 40
+    calls = [(200, 64), (300, 64), (150, 1), (400, 128)]
+    n = n0 + sum(c for c, _ in calls)
+    rows = make_rows(dtype, n, dim, rng)
+    rows[n0 + 10] = rows[5]
+    rows[n0 + 260] = rows[n0 + 20]
+    levels = hx.draw_levels(n, m, seed=3)
+    graphs = []
+    for fused in (True, False):
+        e = hx.Engine(dtype, metric, dim, n)
+        e.append(rows)
+        ix = hx.Index(e, m, efc)
+        ix.insert(0, levels[:n0], batch=256)
+        ix.set_fused(fused)
+        at, elems = n0, []
+        for c, b in calls:
+            elems.append(ix.insert_ondisk(at, levels[at:at + c], batch=b))
+            at += c
+        if fused:
+            assert ix.fused_stats()["redone"] == 0
+        lv = ix.export_levels()
+        layers = [ix.export_layer(l) for l in range(int(max(lv.max(), 0)) + 1)]
+        graphs.append((np.concatenate(elems), lv, ix.entry, layers, [ix.heaptids(i) for i in range(n)]))
+        ix.close()
+        e.close()
+    a, b = graphs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and a[4] == b[4]
+    for (ia, da, ca), (ib, dbb, cb) in zip(a[3], b[3]):
+        assert np.array_equal(ca, cb)
+        valid = np.arange(ia.shape[1])[None, :] < ca[:, None]
+        assert np.array_equal(np.where(valid, ia, 0), np.where(valid, ib, 0))
+        assert np.array_equal(np.where(valid, da.view(np.uint32), 0), np.where(valid, dbb.view(np.uint32), 0))

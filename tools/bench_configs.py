@@ -189,9 +189,11 @@ def run(name, n, data="baseline"):
         ix.search_iterative(nqi, efs, iterative["mode"], iterative["max_scan_tuples"], iterative["limit"], passes)   # first call: allocates the per-query tables (GBs)
         it_first_s = time.perf_counter() - t0
         ix.profile(reset=True)
+        eng.kernel_stats(2, reset=True)
         t0 = time.perf_counter()
         it_tids, it_d, it_cnt = ix.search_iterative(nqi, efs, iterative["mode"], iterative["max_scan_tuples"], iterative["limit"], passes)
         it_s = time.perf_counter() - t0
+        it_k = eng.kernel_stats(2, reset=True)
         it_prof = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ix.profile().items() if k in ("advance_s", "compact_s", "fill_s", "round_s", "rounds")}
         # exact answer under the filter
         sub = torch.nonzero(torch.from_numpy(passes).to(DEV)).squeeze(1)
@@ -219,7 +221,12 @@ def run(name, n, data="baseline"):
         out["iterative_relaxed_first_call_qps"] = round(nqi / it_first_s, 1)
         out["iterative_relaxed"] = {"queries": nqi, "filter": "tid %% %d == 0" % iterative["filter_every"], "max_scan_tuples": iterative["max_scan_tuples"],
                                     "qps": round(nqi / it_s, 1), "recall_at_10": round(recall(it_tids, it_cnt, gti, k), 4),
-                                    "mean_returned": float(it_cnt.mean()), "path": "k_fused MODE 2 (device-resident iterative scan); lock-step host driver when set_fused(False)", "host_profile": it_prof}
+                                    "mean_returned": float(it_cnt.mean()),
+                                    "roofline": {"kernel": "k_fused<OpHamming, 2, 8> (iterative scan, MODE 2)", "bound": "hbm", "bytes_per_distance": row_bytes, "distances": it_k["units"],
+                                                 "kernel_ms": round(it_k["ms"], 2), "achieved": round(it_k["units"] * row_bytes / max(it_k["ms"], 1e-9) / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                                 "frac": round(it_k["units"] * row_bytes / max(it_k["ms"], 1e-9) / 1e6 / 8000.0, 4),
+                                                 "note": "128-byte rows: the scan is bound by the hops of one search (list, visited buckets, heaps, `discarded` bookkeeping), not by bytes"},
+                                    "path": "k_fused MODE 2 (device-resident iterative scan); lock-step host driver when set_fused(False)", "host_profile": it_prof}
     print(json.dumps(out), flush=True)
 
 
