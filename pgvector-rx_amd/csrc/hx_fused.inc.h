@@ -178,7 +178,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     if (ntasks == 0) return fail(HX_E_ARG, "no tasks");
     if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_ARG, "row too wide for the fused kernel");
     const bool ins = mode == 1 || mode == 3;                       // find_element_neighbors (3: search only, W lists out)
-    if (ins && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32 is served by the lock-step path");
+    if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32: the insert kernel's select phase is built for lists of <= 64 (search-only MODE 3 serves every m)");
     if (mode == 3 && (!dev || !dev->d_wl_out || !dev->d_wl_cnt || !dev->h_prob)) return fail(HX_E_ARG, "mode 3 needs the W-list buffers");
     if (mode == 2 && (!it || !it->emask || !it->out_tix)) return fail(HX_E_ARG, "iterative scan arguments missing");
     if (dev && !ins) return fail(HX_E_ARG, "device-resident results are an insert-mode feature");

@@ -422,6 +422,9 @@ struct InsertTask : LsTask {
     std::vector<Cand> ep, w;
     SearchCore sc; SelectTask sel;
     std::vector<std::vector<Cand>> nb;     // selected neighbours per layer 0..new_level
+    // the layers' result sets W (ascending) when the traversal kernel has already searched (MODE 3: m > 32, whose select and back-links the device
+    // kernels do not serve): the task then only runs select_neighbors per layer
+    std::vector<std::vector<Cand>> preset; bool has_preset = false;
 
     bool post_search() { dist_ids = sc.pend; q_sel = id; n_dist += dist_ids.size(); return true; }
     bool advance(const float *dres, const float *pres) override
@@ -431,6 +434,12 @@ struct InsertTask : LsTask {
             switch (st) {
             case S_INIT:
                 nb.assign(new_level + 1, {});
+                if (has_preset) {                                                    // mod.rs:403-427 with W given
+                    lc = std::min(new_level, entry_level);
+                    if (lc < 0) { st = S_DONE; break; }
+                    w = preset[lc]; sel.start(&w, (size_t)g->lm(lc)); st = S_SELECT; pres = nullptr;
+                    break;
+                }
                 dist_ids.push_back(entry); q_sel = id; n_dist += 1; st = S_ENTRY;    // mod.rs:371-377
                 return true;
             case S_ENTRY:
@@ -463,6 +472,12 @@ struct InsertTask : LsTask {
             case S_SELECT:                                                           // mod.rs:419-425
                 { const float *pp = pres; pres = nullptr; if (sel.step(pp, *this)) return true; }
                 nb[lc] = sel.R;
+                if (has_preset) {
+                    lc--;
+                    if (lc < 0) { st = S_DONE; break; }
+                    w = preset[lc]; sel.start(&w, (size_t)g->lm(lc)); pres = nullptr;
+                    break;
+                }
                 ep = w;
                 lc--;
                 st = S_SEARCH;
@@ -1144,6 +1159,67 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
         }
         ix->fused_tasks += n; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
+    } else if (ix->fused && 2 * g.m > 64 && ix->e->pitch <= 8192 && ix->e->dtype != HX_SPARSE && hi > lo) {
+        // m > 32 (the reference allows m <= 100, options.rs:203-225): the insert-mode select and the back-link kernels are built for lists of <= 64, but
+        // the searches -- the bulk of the distance evaluations -- run in the traversal kernel all the same (MODE 3 walks lists longer than a wavefront
+        // 64 ids at a time and hands out every layer's W); select_neighbors and update_neighbor_connections follow on the lock-step driver.
+        int rc = ix->sync_mirror();
+        if (rc) return rc;
+        hx_engine *e = ix->e;
+        const uint32_t n = hi - lo;
+        std::vector<uint32_t> qsel(n), prob(n), tstat(n); std::vector<int32_t> tl(n);
+        uint32_t P = 0;
+        for (uint32_t i = 0; i < n; i++) { qsel[i] = bs.base + lo + i; tl[i] = g.level[bs.base + lo + i]; prob[i] = P; P += (uint32_t)std::min(tl[i], bs.entry_level) + 1u; }
+        if ((rc = e->wsel_reserve(P, (uint32_t)ix->efc)) || (rc = e->db_reserve_records(n))) return ix->fail(rc, e->err);
+        HxWselWork &w = e->wsel;
+        if (hipMemsetAsync(w.d_cnt, 0, (size_t)P * 4, e->stream) != hipSuccess) return ix->fail(HX_E_HIP, "clearing the W counts failed");
+        HxFusedDev dev; dev.d_rec = e->bw.d_rec; dev.rec_words = hx_rec_words((uint32_t)g.m); dev.h_slots = nullptr;
+        dev.d_wl_out = w.d_wl; dev.d_wl_cnt = w.d_cnt; dev.h_prob = prob.data();
+        uint64_t cnts[2] = {0, 0};
+        const double t0 = hx_index::now_s();
+        if ((rc = e->fused_run(3, n, qsel.data(), tl.data(), (uint32_t)ix->efc, 0, bs.entry, bs.entry_level,
+                               nullptr, nullptr, nullptr, tstat.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, e->err);
+        ix->prof[6] += hx_index::now_s() - t0;
+        ix->counters[1] += cnts[0];
+        std::vector<uint32_t> wcnt(P); std::vector<uint2> wl((size_t)P * ix->efc);
+        if (hipMemcpyAsync(wcnt.data(), w.d_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipMemcpyAsync(wl.data(), w.d_wl, (size_t)P * ix->efc * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess) return ix->fail(HX_E_HIP, "reading the W lists failed");
+        std::vector<std::unique_ptr<InsertTask>> &its = ix->insert_pool;
+        while (its.size() < n) its.emplace_back(new InsertTask());
+        std::vector<LsTask *> tasks; std::vector<uint32_t> members;
+        for (uint32_t i = 0; i < n; i++) {
+            if (tstat[i] != 0) { todo.push_back(lo + i); continue; }
+            InsertTask &t = *its[tasks.size()];
+            t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
+            t.g = &g; t.id = bs.base + lo + i; t.new_level = tl[i]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
+            const int start = std::min(tl[i], bs.entry_level);
+            t.preset.assign(start + 1, {}); t.has_preset = true;
+            for (int lc = 0; lc <= start; lc++) {
+                const size_t pr = (size_t)prob[i] + (size_t)lc; const uint2 *W = wl.data() + pr * ix->efc;
+                t.preset[lc].resize(wcnt[pr]);
+                for (uint32_t k = 0; k < wcnt[pr]; k++) { memcpy(&t.preset[lc][k].d, &W[k].x, 4); t.preset[lc][k].id = W[k].y; }
+            }
+            if (ix->mfma_on()) { int rcn = e->mfma_norms(e->n_rows); if (rcn) return ix->fail(rcn, e->err); }
+            ix->arm_select(t.sel);
+            tasks.push_back(&t); members.push_back(lo + i);
+        }
+        if ((rc = ix->run_lockstep(tasks))) return rc;
+        for (size_t ti = 0; ti < tasks.size(); ti++) {
+            InsertTask &t = *its[ti];
+            for (int lc = 0; lc <= t.new_level; lc++) {
+                Cand *lst = g.list(t.id, lc);
+                for (size_t k = 0; k < t.nb[lc].size(); k++) lst[k] = t.nb[lc][k];
+                g.cnt(t.id, lc) = (uint16_t)t.nb[lc].size();
+            }
+            t.has_preset = false; t.preset.clear();
+            ix->counters[1] += t.n_dist; ix->counters[2] += t.n_pair;
+            ix->mfma_pairs += t.sel.n_mfma; ix->mfma_exact += t.sel.n_exact;
+            ix->mark_dirty(t.id);
+            bs.searched[members[ti]] = 1;
+        }
+        ix->fused_tasks += n; ix->fused_redo += todo.size();
+        if (todo.empty()) return HX_OK;
     } else {
         for (uint32_t i = lo; i < hi; i++) todo.push_back(i);
     }
@@ -1153,6 +1229,7 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
     for (size_t ti = 0; ti < todo.size(); ti++) {
         const uint32_t i = todo[ti];
         InsertTask &t = *its[ti];
+        t.has_preset = false;
         t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
         t.g = &g; t.id = bs.base + i; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
         if (ix->mfma_on()) { int rcn = ix->e->mfma_norms(ix->e->n_rows); if (rcn) return ix->fail(rcn, ix->e->err); }
@@ -1581,6 +1658,7 @@ int hx_index_dbatch_search(hx_index *ix, uint32_t lo, uint32_t hi, void *d_recor
     std::vector<LsTask *> tasks(todo.size());
     for (size_t ti = 0; ti < todo.size(); ti++) {
         InsertTask &t = *its[ti];
+        t.has_preset = false;
         t.st = InsertTask::S_INIT; t.lc = 0; t.n_dist = t.n_pair = 0; t.clear_req();
         t.g = &g; t.id = bs.base + lo + todo[ti]; t.new_level = g.level[t.id]; t.entry = bs.entry; t.entry_level = bs.entry_level; t.efc = ix->efc;
         if (ix->mfma_on()) { int rcn = ix->e->mfma_norms(ix->e->n_rows); if (rcn) return ix->fail(rcn, ix->e->err); }

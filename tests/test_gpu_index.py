@@ -851,3 +851,28 @@ def test_pipelined_scans_equal_the_plain_scan(dtype, metric, dim, monkeypatch):
         assert ref[0][q, :ref[3][q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=efs, limit=k)]
     ix.close()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,metric,dim,n,m,efc,batch", [(hx.F32, hx.L2SQ, 24, 1500, 40, 80, 64), (hx.F32, hx.NEG_IP, 300, 900, 64, 128, 100),
+                                                        (hx.BIT, hx.HAMMING, 128, 1200, 100, 200, 50), (hx.F16, hx.L1, 12, 1000, 50, 120, 37)])
+def test_m_above_32_searches_in_the_traversal_kernel(dtype, metric, dim, n, m, efc, batch):
+    """m in 33..100 (options.rs:203-225; lists of up to 200): the searches of the build run in the traversal kernel (MODE 3: lists longer than a
+    wavefront are walked 64 ids at a time, every layer's W handed out); select_neighbors and the back-links follow on the lock-step driver.
+    Graph, duplicates and scans equal the oracle's."""
+    rng = np.random.default_rng(m * 7 + dim)
+    rows = make_rows(dtype, n, dim, rng)
+    rows[n // 2] = rows[3]
+    levels = hx.draw_levels(n, m, seed=19)
+    e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, batch, True)
+    assert elem.tolist() == oelem.tolist()
+    st = ix.fused_stats()
+    assert st["tasks"] > n // 2 and st["redone"] == 0                    # the members' searches were device tasks
+    assert_same_graph(ix, o, n)
+    qs = make_rows(dtype, 10, dim, rng)
+    e.set_queries(qs)
+    tids, d, el, cnt = ix.search(10, 40, 10)
+    for q in range(10):
+        assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=40, limit=10)]
+    ix.close()
+    e.close()
