@@ -28,7 +28,7 @@ import torch
 import os
 
 STAGE_SECONDS = {}      # wall time per stage of the last insert_sharded call (rank-local, for bench.py's report)
-WTAB_EXCHANGE = os.environ.get("HX_DIST_WTABS", "1") != "0"
+WTAB_EXCHANGE = int(os.environ.get("HX_DIST_WTABS", "1"))   # 1: exchange the W tables when the data path is RCCL (over gloo's host staging they cost more than they save); 2: always (tests); 0: never
 
 
 class Comm:
@@ -170,8 +170,8 @@ def _device_batch(ix, first_row, levels, tids, dist, device, gpu, world, rank):
     recs = all_gather_device(send, world, dist, device)
     t0 = _t("allgather_new", t0)
     # the members' W tables travel too (4 KB each at ef_construction 200): every rank then prunes the lists it owns with the look-ups a single GPU
-    # has for ALL members instead of streaming the rows of the members other ranks searched (HX_DIST_WTABS=0: off)
-    wb = getattr(ix, "dbatch_wtab_bytes", 0) if WTAB_EXCHANGE and world > 1 else 0
+    # has for ALL members instead of streaming the rows of the members other ranks searched (HX_DIST_WTABS: see above)
+    wb = getattr(ix, "dbatch_wtab_bytes", 0) if world > 1 and (WTAB_EXCHANGE == 2 or (WTAB_EXCHANGE == 1 and torch.device(device).type == "cuda")) else 0
     if wb:
         wsend = torch.zeros(per * wb, dtype=torch.uint8, device=gpu)
         if on_gpu:

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+os.environ.setdefault("HX_DIST_WTABS", "2")      # exchange the W tables also over the gloo staging of these one-GPU rehearsals
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pgvector_rx_amd as hx  # noqa: E402
 
