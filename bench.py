@@ -54,6 +54,7 @@ def parse():
     p.add_argument("--no-k1-1536", action="store_true", help="skip the K1 micro-benchmark on a vector(1536) table")
     p.add_argument("--no-query-sweep", action="store_true", help="skip the 2x / 4x query-batch lines")
     p.add_argument("--no-pipeline", action="store_true", help="one scan launch at a time (hx_index_search) instead of submitting step i+1 before collecting step i")
+    p.add_argument("--slots", type=int, default=2, choices=[2, 3, 4], help="scan slots (= query batches resident in HBM) the pipelined steps rotate over: step i+slots-1 is submitted before step i is collected")
     p.add_argument("--no-efs-sweep", action="store_true", help="skip the ef_search 40 / 200 lines (BASELINE.md C2 lists 40, 100, 200)")
     p.add_argument("--no-fused", action="store_true", help="run every traversal in the lock-step host driver")
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -235,30 +236,34 @@ def run(a, json_fd):
     build_prof = ix.profile(reset=True)
 
     # ---- search steps ----
-    # two query batches resident in HBM; step i scans batch i % 2
-    queries_b, _ = synth(a.queries, a.dim, a.dist, 14 + 1000 * rank, dev, centres)
-    qboth = torch.cat([queries, queries_b])
+    # a.slots query batches resident in HBM; step i scans batch i % slots
+    qbatches = [queries] + [synth(a.queries, a.dim, a.dist, 14 + j + 1000 * rank, dev, centres)[0] for j in range(a.slots - 1)]
+    queries_b = qbatches[1]
+    qboth = torch.cat(qbatches)
     torch.cuda.synchronize()
-    eng.set_queries_device(qboth.data_ptr(), 2 * a.queries)
+    eng.set_queries_device(qboth.data_ptr(), a.slots * a.queries)
     pipelined = not a.no_pipeline and not a.no_fused
+    S = a.slots
 
     def run_steps(n, efs):
-        """n steps; returns the last results of batch 0 and batch 1 (each step's results are complete on the host when it ends)"""
-        res = [None, None]
+        """n steps; returns the last results per query batch (each step's results are complete on the host when it ends)"""
+        res = [None] * S
         if not pipelined:
             for i in range(n):
-                eng_first = (i % 2) * a.queries
-                if eng_first:     # plain scans read query slots 0..nq-1: batch B is scanned through a submit on slot 0 + wait (no overlap)
+                eng_first = (i % S) * a.queries
+                if eng_first:     # plain scans read query slots 0..nq-1: the other batches are scanned through a submit on slot 0 + wait (no overlap)
                     ix.search_submit(0, eng_first, a.queries, efs, a.k)
-                    res[1] = ix.search_wait(0)
+                    res[i % S] = ix.search_wait(0)
                 else:
                     res[0] = ix.search(a.queries, efs, a.k)
             return res
-        ix.search_submit(0, 0, a.queries, efs, a.k)
+        for j in range(min(S - 1, n)):
+            ix.search_submit(j % S, (j % S) * a.queries, a.queries, efs, a.k)
         for i in range(n):
-            if i + 1 < n:
-                ix.search_submit((i + 1) % 2, ((i + 1) % 2) * a.queries, a.queries, efs, a.k)
-            res[i % 2] = ix.search_wait(i % 2)
+            j = i + S - 1
+            if j < n:
+                ix.search_submit(j % S, (j % S) * a.queries, a.queries, efs, a.k)
+            res[i % S] = ix.search_wait(i % S)
         return res
 
     run_steps(a.warmup, a.efs)
@@ -348,13 +353,13 @@ def run(a, json_fd):
             gb = st["units"] * a.dim * 4 / max(st["ms"], 1e-9) / 1e6
             sweep.append({"queries_per_launch": nq, "qps": round(nq / dq, 1), "kernel_ms": round(st["ms"] / max(1, st["launches"]), 3),
                           "achieved": round(gb, 1), "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBPS, 4)})
-        eng.set_queries_device(qboth.data_ptr(), 2 * a.queries)
+        eng.set_queries_device(qboth.data_ptr(), a.slots * a.queries)
         del big
 
     gt = ground_truth(rows, queries, a.k)
     gt_b = ground_truth(rows, queries_b, a.k)
     hits_n, hits_d = 0.0, 0
-    for r, g_ in ((results[0], gt), (results[1], gt_b)):
+    for r, g_ in ((results[0], gt), (results[1], gt_b)):              # (batches beyond the second are scanned and timed like these two; recall is taken on two)
         if r is not None:
             hits_n += recall_at_k(r[0], r[3], g_, a.k) * g_.shape[0]
             hits_d += g_.shape[0]
@@ -534,7 +539,7 @@ def run(a, json_fd):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: %d x vector(%d) L2, m=%d ef_construction=%d, build + search on %d MI355X" % (a.rows, a.dim, a.m, a.efc, world),
                    "distribution": a.dist, "ef_search": a.efs, "k": a.k, "queries_per_step": a.queries,
-                   "steps_pipelined": bool(pipelined), "query_batches_resident": 2,
+                   "steps_pipelined": bool(pipelined), "query_batches_resident": a.slots,
                    "insert_batch_cap": eff_batch, "host_threads": a.threads or min(16, os.cpu_count() or 1)},
         "build_sec": round(build_sec, 2),
         "build_rows_per_s": round(a.rows / build_sec, 1),
