@@ -68,3 +68,36 @@ def test_slice_bounds_and_schedule():
     for b in s:
         assert b <= max(1, size // 8)
         size += b
+
+
+def test_bench_launcher_takes_the_other_ranks_down_when_one_dies():
+    """`python bench.py --gpus N` started without a launcher watches the rank processes it starts: the first one that exits non-zero ends the others and
+    the launcher exits non-zero within seconds -- nobody is left inside a collective waiting for a dead peer (here: no GPU, so every rank dies at
+    torch.cuda.set_device; on a GPU box a rank that faults mid-build takes the same path)."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check needs a box without a GPU (the ranks must fail)")
+    root = os.path.dirname(HERE)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--rows", "1000", "--queries", "10", "--no-cpu"],
+                         cwd=root, capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0
+    assert "the other ranks were stopped" in out.stderr, out.stderr[-1500:]
+    assert out.stdout.strip() == ""                                     # no JSON line from a failed job
+    assert time.time() - t0 < 200
+
+
+def test_bring_up_agrees_on_gloo_when_rccl_is_not_asked_for():
+    """dist_build.bring_up(want="gloo") with two ranks on CPU: rendezvous with an explicit timeout, a Comm over the world group, collectives work."""
+    port = free_port()
+    code = ("import os, sys, importlib, torch; sys.path.insert(0, %r); db = importlib.import_module('pgvector-rx_amd.dist_build'); "
+            "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']); c, dev = db.bring_up(r, w, torch.device('cpu'), want='gloo', gloo_timeout_s=60); "
+            "t = torch.tensor([r + 1]); c.all_reduce(t); out = torch.empty(w, dtype=torch.int64); c.all_gather_into_tensor(out, torch.tensor([r])); "
+            "print('OK', c.backend, dev.type, int(t.item()), out.tolist(), c.get_world_size(), c.get_rank())") % os.path.dirname(HERE)
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    for r, p in enumerate(procs):
+        o, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, o
+        assert "OK gloo cpu 3 [0, 1] 2 %d" % r in o, o
