@@ -17,6 +17,7 @@ SOURCES = {
     "hx_fused_f32.hip": ["hx_ops.h", "hx_fused_core.h", "hx_fused_kernel.h"],
     "hx_fused_f16.hip": ["hx_ops.h", "hx_fused_core.h", "hx_fused_kernel.h"],
     "hx_fused_bit.hip": ["hx_ops.h", "hx_fused_core.h", "hx_fused_kernel.h"],
+    "hx_fused_sparse.hip": ["hx_ops.h", "hx_fused_core.h", "hx_fused_kernel.h"],
     "hx_links.hip": ["hx_ops.h", "hx_fused_core.h"],
     "hx_mfma.hip": ["hx_ops.h"],
     "hx_sparse.hip": ["hx_ops.h"],

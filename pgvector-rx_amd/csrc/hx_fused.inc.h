@@ -178,6 +178,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     if (ntasks == 0) return fail(HX_E_ARG, "no tasks");
     if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_ARG, "row too wide for the fused kernel");
     const bool ins = mode == 1 || mode == 3;                       // find_element_neighbors (3: search only, W lists out)
+    if (dtype == HX_SPARSE && mode == 1) return fail(HX_E_ARG, "sparsevec: the traversal kernel serves scans and search-only inserts (modes 0, 2, 3)");
     if (mode == 1 && 2 * mr.m > 64) return fail(HX_E_ARG, "m > 32: the insert kernel's select phase is built for lists of <= 64 (search-only MODE 3 serves every m)");
     if (mode == 3 && (!dev || !dev->d_wl_out || !dev->d_wl_cnt || !dev->h_prob)) return fail(HX_E_ARG, "mode 3 needs the W-list buffers");
     if (mode == 2 && (!it || !it->emask || !it->out_tix)) return fail(HX_E_ARG, "iterative scan arguments missing");
@@ -313,6 +314,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     p.status = (uint32_t *)(io.d_io + o_st);
     p.o_cst = FUSED_MAXL; p.o_lst = FUSED_MAXL * 2 * mr.m; p.t_oslot = nullptr;
     p.wtab = nullptr; p.wt_size = 0; p.wt_slot0 = 0; p.wt_valid = nullptr;
+    p.sparse_cap = dtype == HX_SPARSE ? (uint32_t)std::min(dim, HX_SPARSE_MAX_NNZ) : 0u;
     p.wl_out = nullptr; p.wl_cnt = nullptr; p.t_prob = nullptr; p.ondisk = (mode == 3 && dev && dev->ondisk) ? 1u : 0u;
     if (mode == 3) { p.wl_out = (uint2 *)dev->d_wl_out; p.wl_cnt = dev->d_wl_cnt; p.t_prob = (const uint32_t *)(io.d_io + o_prob); }
     if (dev && dev->d_wtab) { p.wtab = (uint2 *)dev->d_wtab; p.wt_size = dev->wt_size; p.wt_slot0 = dev->wt_slot0; p.wt_valid = dev->d_wt_valid; }
@@ -330,7 +332,8 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     hipError_t ls = hipSuccess;
     fused_stream = stream;
     ls = dtype == HX_F32 ? hx_launch_fused_f32(this, metric, p, grid, lds, mode)
-            : dtype == HX_F16 ? hx_launch_fused_f16(this, metric, p, grid, lds, mode) : hx_launch_fused_bit(this, metric, p, grid, lds, mode);
+            : dtype == HX_F16 ? hx_launch_fused_f16(this, metric, p, grid, lds, mode)
+            : dtype == HX_SPARSE ? hx_launch_fused_sparse(this, metric, p, grid, lds, mode) : hx_launch_fused_bit(this, metric, p, grid, lds, mode);
     HX_HIP(this, ls);
     if (timing) HX_HIP(this, hipEventRecord(io.ev1, stream));
     HX_HIP(this, hipMemcpyAsync(io.h_io + o_ctr, io.d_io + o_ctr, 256, hipMemcpyDeviceToHost, stream));

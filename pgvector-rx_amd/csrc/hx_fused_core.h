@@ -56,6 +56,7 @@ struct FusedParams {
     // MODE 3 (insert, search only: select_neighbors runs on the matrix cores afterwards, hx_mfma.hip): the sorted result set W of layer lc of task t goes to
     // problem t_prob[t] + lc: wl_out[problem * ef + i] = {distance bits, id}, wl_cnt[problem] = |W|
     uint2 *wl_out; uint32_t *wl_cnt; const uint32_t *t_prob;
+    uint32_t sparse_cap;                          // sparsevec (OpSparse): index / value slots per row record
     uint32_t ondisk;                              // MODE 3 for aminsert: search_layer_disk semantics (W handed out nearest LAST, as scan.rs:441-446 sorts it)
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
     // iterative scan (k_fused MODE 2): hnsw.iterative_scan relaxed_order (1) / strict_order (2), scan.rs:794-875
@@ -79,11 +80,12 @@ __device__ __forceinline__ KParams &f_params_here(KParams &p) { KParams *q = &p;
 hipError_t hx_launch_fused_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_f16(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
+hipError_t hx_launch_fused_sparse(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);   // modes 0, 2, 3 (scans and search-only inserts)
 
 // what the query-vs-rows helpers below need: the row store and 64 floats of LDS scratch for the short-row path.  Kept apart from FusedParams
 // so that the kernel's parameters stay an immutable kernel argument (fields are s_load-ed from the kernarg segment where they are used instead of
 // the whole struct being held live in scalar registers -- it was copied to a mutable local for the sake of `dsc`, and spilled)
-struct FRows { const uint8_t *rows; uint32_t pitch, nch; float *dsc; };
+struct FRows { const uint8_t *rows; uint32_t pitch, nch; float *dsc; uint32_t cap = 0; };   // cap: sparsevec records only (slots per record)
 
 struct FHeapItem { float d; uint32_t id; };
 __device__ __forceinline__ uint2 fh_pack(float d, uint32_t id) { return make_uint2(__builtin_bit_cast(unsigned int, d), id); }
@@ -404,6 +406,11 @@ template <int LPR> __device__ __forceinline__ constexpr uint32_t f_step_rows() {
 template <class OP, int LPR, int RB = FUSED_RB>
 __device__ __forceinline__ float f_dist_batch(const FRows &p, const lds_u8 *qv, const uint32_t *ids, uint32_t n, uint32_t lane, uint32_t *tk = nullptr)
 {
+    if constexpr (OP::kSparse) {     // sparsevec: lane j walks the merge join of (parked query record, row ids[j]) in the reference's own order (hx_ops.h: sp_merge)
+        float d = 0.0f;
+        if (lane < n) d = sp_merge<OP::kind>(sp_row((const uint8_t *)qv, p.cap), sp_row(p.rows + (size_t)ids[lane] * p.pitch, p.cap));   // distance(query, element), graph/mod.rs:221
+        return d;
+    } else {
     if constexpr (LPR < 64) return f_dist_small<OP, LPR>(p, qv, ids, n, lane);
     float mine = 0.0f;
     unsigned long long tq = tk ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -485,6 +492,7 @@ __device__ __forceinline__ float f_dist_batch(const FRows &p, const lds_u8 *qv, 
     }
     return mine;
 #undef FD_TICK
+    }
 }
 
 // check_element_closer (graph/mod.rs:315-339): is any d(q, ids[j]) <= thr?  Rows are evaluated FUSED_RB at a time in list

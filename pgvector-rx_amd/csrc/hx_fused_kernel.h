@@ -465,7 +465,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
 
     for (;;) {
         KParams &p = f_params_here(p_in);                  // per task: what the task derives from the parameters does not outlive it
-        cx.fr.rows = p.rows; cx.fr.pitch = p.pitch; cx.fr.nch = p.nch;
+        cx.fr.rows = p.rows; cx.fr.pitch = p.pitch; cx.fr.nch = p.nch; cx.fr.cap = p.sparse_cap;
         if (lane == 0) cx.CTL[5] = atomicAdd(p.next_task, 1u);
         F_BAR();
         const uint32_t t = cx.CTL[5];

@@ -824,7 +824,7 @@ struct hx_index {
     bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192 && e->dtype != HX_SPARSE; }   // sparsevec: lock-step driver (merge-join kernels)
     // scans: the traversal kernel walks lists longer than a wavefront 64 ids at a time, so every m the reference allows (options.rs:203-225: m <= 100) is served;
     // only the insert-mode kernel and the back-link kernels are built for lists of <= 64
-    bool fused_scan_ok() const { return fused && e->pitch <= 8192 && e->dtype != HX_SPARSE; }
+    bool fused_scan_ok() const { return fused && e->pitch <= 8192; }   // round 3: sparsevec too (hx_fused_sparse.hip: one lane per row walks the merge join)
     // device-resident batches (hx_batch.hip): the traversal kernel and the back-link kernels both serve this m
     bool dbatch_ok() const { static const bool off = getenv("HX_DEVICE_BATCH") && atoi(getenv("HX_DEVICE_BATCH")) == 0; return !off && fused_ok() && 2 * g.m <= 64; }
     void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
@@ -1159,8 +1159,9 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
         }
         ix->fused_tasks += n; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
-    } else if (ix->fused && 2 * g.m > 64 && ix->e->pitch <= 8192 && ix->e->dtype != HX_SPARSE && hi > lo) {
-        // m > 32 (the reference allows m <= 100, options.rs:203-225): the insert-mode select and the back-link kernels are built for lists of <= 64, but
+    } else if (ix->fused && (2 * g.m > 64 || ix->e->dtype == HX_SPARSE) && ix->e->pitch <= 8192 && hi > lo) {
+        // m > 32 (the reference allows m <= 100, options.rs:203-225) and sparsevec rows: the insert-mode select and the back-link kernels are built for lists of
+        // <= 64 and for dense rows, but
         // the searches -- the bulk of the distance evaluations -- run in the traversal kernel all the same (MODE 3 walks lists longer than a wavefront
         // 64 ids at a time and hands out every layer's W); select_neighbors and update_neighbor_connections follow on the lock-step driver.
         int rc = ix->sync_mirror();
@@ -1889,7 +1890,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
         std::vector<int> mlv(b);
         for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[done + i], mxl); if (lv < 0) lv = 0; mlv[i] = lv; nbs[i].assign(lv + 1, {}); }
         std::vector<uint32_t> ls_members;                                            // members for the lock-step driver
-        if (ix->fused_ok() && !any_deleted && b >= 1) {
+        if (ix->fused_scan_ok() && !any_deleted && b >= 1) {
             if ((rc = ix->sync_mirror())) return rc;
             hx_engine *e = ix->e;
             std::vector<uint32_t> qsel(b), prob(b), tstat(b); std::vector<int32_t> tl(b);

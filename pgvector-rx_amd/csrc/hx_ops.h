@@ -82,6 +82,7 @@ template <int KIND> __device__ __forceinline__ void fterm(float &acc, float x, f
 }
 
 template <int KIND> struct OpF32 {
+    static constexpr bool kSparse = false;
     static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = true;    // real-valued distances: ties are rare enough for k_fused's sorted-array searches
     typedef float acc_t;
@@ -101,6 +102,7 @@ template <int KIND> struct OpF32 {
 };
 
 template <int KIND> struct OpF16 {
+    static constexpr bool kSparse = false;
     static constexpr bool mfma_split_ok = KIND == K_IP;   // k_fused MODE 3: select_neighbors on the matrix cores (halfvec inner product is a true f16 GEMM)
     static constexpr bool sorted_array_ok = true;
     typedef float acc_t;
@@ -123,6 +125,7 @@ template <int KIND> struct OpF16 {
 };
 
 struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
+    static constexpr bool kSparse = false;
     static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = false;   // integer-valued: ties everywhere, the heap kernels only
     typedef int acc_t;
@@ -139,6 +142,7 @@ struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
 
 struct JacAcc { int ab, aa, bb; };
 struct OpJaccard {   // bitvec.rs:113-132
+    static constexpr bool kSparse = false;
     static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = false;
     typedef JacAcc acc_t;
@@ -205,6 +209,58 @@ __device__ __forceinline__ void reduce_pairs(typename OP::acc_t (&acc)[NP], uint
 #define HX_PAIRS_PER_WAVE 66
 #define HX_PAIR_SLAB (HX_PAIR_WAVES * HX_PAIRS_PER_WAVE)   /* 528 = 33*32/2 */
 
+
+// ---- sparsevec rows (hx_sparse.hip, and the traversal kernel's sparse distance path) ----------------------------------------------------
+// Row record: { int32 nnz; int32 pad[3]; int32 index[cap]; float value[cap] }, cap = min(dim, 1000).  A distance is a merge join of two ascending
+// index lists (src/types/sparsevec.rs:873-950, 1038-1088), its f32 terms added in merged-index order: ONE LANE walks one pair with the reference's own loop.
+struct SpRow { const int32_t *idx; const float *val; int nnz; };
+template <class P> __device__ __forceinline__ SpRow sp_row(P rec, uint32_t cap)
+{
+    SpRow r; r.nnz = *(const int32_t *)rec; r.idx = (const int32_t *)(rec + 16); r.val = (const float *)(rec + 16 + (size_t)cap * 4); return r;
+}
+// KIND: K_L2 sparse_l2_squared_distance (sparsevec.rs:873-918), K_IP sparse_inner_product (:921-950), K_L1 sparsevec_l1_distance (:1038-1088)
+template <int KIND>
+__device__ float sp_merge(const SpRow a, const SpRow b)
+{
+    float distance = 0.0f;
+    int bpos = 0;
+    for (int i = 0; i < a.nnz; i++) {
+        const int32_t ai = a.idx[i];
+        int32_t bi = -1;
+        for (int j = bpos; j < b.nnz; j++) {
+            bi = b.idx[j];
+            if (ai == bi) {
+                if (KIND == K_L2) { const float diff = a.val[i] - b.val[j]; distance += diff * diff; }
+                else if (KIND == K_IP) distance += a.val[i] * b.val[j];
+                else distance += __builtin_fabsf(a.val[i] - b.val[j]);
+            } else if (ai > bi) {
+                if (KIND == K_L2) distance += b.val[j] * b.val[j];
+                else if (KIND == K_L1) distance += __builtin_fabsf(b.val[j]);
+            }
+            if (ai >= bi) bpos = j + 1;
+            if (bi >= ai) break;
+        }
+        if (ai != bi) {
+            if (KIND == K_L2) distance += a.val[i] * a.val[i];
+            else if (KIND == K_L1) distance += __builtin_fabsf(a.val[i]);
+        }
+    }
+    if (KIND != K_IP)
+        for (int j = bpos; j < b.nnz; j++) {
+            if (KIND == K_L2) distance += b.val[j] * b.val[j]; else distance += __builtin_fabsf(b.val[j]);
+        }
+    return KIND == K_IP ? -distance : distance;           // sparsevec_negative_inner_product, sparsevec.rs:993-1003
+}
+// the traversal kernel's view of the type: no chunk-wise accumulation -- f_dist_batch hands a row batch to f_dist_sparse (one lane per row)
+template <int KIND> struct OpSparse {
+    static constexpr bool kSparse = true, mfma_split_ok = false, sorted_array_ok = false, kFloatAcc = false;
+    static constexpr int kind = KIND;
+    typedef float acc_t;
+    static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
+    static __device__ __forceinline__ void add(acc_t &, const u4 &, const u4 &) {}
+    template <int LPR> static __device__ __forceinline__ float finish(acc_t a) { return a; }
+    static __device__ __forceinline__ float post(float s) { return s; }
+};
 __device__ __forceinline__ void tri_decode(uint32_t p, uint32_t &i, uint32_t &j)
 {   // p = i*(i-1)/2 + j, j < i
     uint32_t ii = (uint32_t)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);

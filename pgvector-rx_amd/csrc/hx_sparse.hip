@@ -10,46 +10,6 @@
 
 namespace {
 
-struct SpRow { const int32_t *idx; const float *val; int nnz; };
-template <class P> __device__ __forceinline__ SpRow sp_row(P rec, uint32_t cap)
-{
-    SpRow r; r.nnz = *(const int32_t *)rec; r.idx = (const int32_t *)(rec + 16); r.val = (const float *)(rec + 16 + (size_t)cap * 4); return r;
-}
-
-// KIND: K_L2 sparse_l2_squared_distance (sparsevec.rs:873-918), K_IP sparse_inner_product (:921-950), K_L1 sparsevec_l1_distance (:1038-1088)
-template <int KIND>
-__device__ float sp_merge(const SpRow a, const SpRow b)
-{
-    float distance = 0.0f;
-    int bpos = 0;
-    for (int i = 0; i < a.nnz; i++) {
-        const int32_t ai = a.idx[i];
-        int32_t bi = -1;
-        for (int j = bpos; j < b.nnz; j++) {
-            bi = b.idx[j];
-            if (ai == bi) {
-                if (KIND == K_L2) { const float diff = a.val[i] - b.val[j]; distance += diff * diff; }
-                else if (KIND == K_IP) distance += a.val[i] * b.val[j];
-                else distance += __builtin_fabsf(a.val[i] - b.val[j]);
-            } else if (ai > bi) {
-                if (KIND == K_L2) distance += b.val[j] * b.val[j];
-                else if (KIND == K_L1) distance += __builtin_fabsf(b.val[j]);
-            }
-            if (ai >= bi) bpos = j + 1;
-            if (bi >= ai) break;
-        }
-        if (ai != bi) {
-            if (KIND == K_L2) distance += a.val[i] * a.val[i];
-            else if (KIND == K_L1) distance += __builtin_fabsf(a.val[i]);
-        }
-    }
-    if (KIND != K_IP)
-        for (int j = bpos; j < b.nnz; j++) {
-            if (KIND == K_L2) distance += b.val[j] * b.val[j]; else distance += __builtin_fabsf(b.val[j]);
-        }
-    return KIND == K_IP ? -distance : distance;           // sparsevec_negative_inner_product, sparsevec.rs:993-1003
-}
-
 // query-vs-rows: one wavefront per expansion group, the query record parked in LDS, lane l walks rows l, l + 64, ...
 template <int KIND>
 __global__ void __launch_bounds__(64)

@@ -92,11 +92,13 @@ def test_sparse_normalize_bit_exact():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["traversal-kernel", "lock-step"])
 @pytest.mark.parametrize("metric,cosine", [(hx.L2SQ, False), (hx.NEG_IP, False), (hx.L1, False), (hx.NEG_IP, True)])
-def test_sparse_index_equals_oracle(metric, cosine):
+def test_sparse_index_equals_oracle(metric, cosine, fused):
     """Build + scan of an HNSW index on sparsevec rows (sparsevec_l2_ops / _ip_ops / _l1_ops / _cosine_ops, sparsevec.rs:1552-1582): graph and
     top-k identical to the oracle's; the reference's own 4-row orderings (tests/pg_regress/expected/hnsw_sparsevec.out) are pinned on the oracle
-    in tests/test_oracle_golden.py."""
+    in tests/test_oracle_golden.py.  Round 3: the searches of the build and the scans run in the traversal kernel (hx_fused_sparse.hip: one lane per
+    row walks the merge join); `lock-step` is the round-2 placement on the merge-join kernels."""
     rng = np.random.default_rng(11 + metric + cosine)
     dim, n, m, efc = 400, 600, 8, 40
     rows = random_sparse(rng, n, dim, 30)
@@ -120,6 +122,7 @@ def test_sparse_index_equals_oracle(metric, cosine):
     levels = hx.draw_levels(nk, m, seed=3)
     tids = np.arange(nk, dtype=np.int64)
     ix = hx.Index(e, m, efc)
+    ix.set_fused(fused)
     elem = ix.insert(0, levels, tids=tids, batch=1)
     oelem = np.concatenate([o.insert_batch(rec[i:i + 1], levels[i:i + 1], tids[i:i + 1]) for i in range(nk)])   # batch of one = the reference's schedule
     assert elem.tolist() == oelem.tolist()
@@ -143,7 +146,14 @@ def test_sparse_index_equals_oracle(metric, cosine):
         res = o.scan(qs[q], ef_search=40, limit=10)
         assert t[q, :cnt[q]].tolist() == [x for x, _, _ in res]
         assert (d[q, :cnt[q]].view(np.uint32) == np.array([y for _, y, _ in res], np.float32).view(np.uint32)).all()
-    assert ix.fused_stats()["tasks"] == 0                                           # served by the lock-step driver on the merge-join kernels
+    st = ix.fused_stats()
+    assert (st["tasks"] >= nk and st["redone"] == 0) if fused else st["tasks"] == 0    # the searches were device tasks / the lock-step driver on the merge-join kernels
+    # iterative scans (relaxed and strict order) on the same placement
+    for mode in (1, 2):
+        ti, di, ci = ix.search_iterative(12, 10, mode, 200, 15)
+        for q in range(12):
+            want = o.scan(qs[q], ef_search=10, iterative=orc.ITER_RELAXED if mode == 1 else orc.ITER_STRICT, max_scan_tuples=200)[:15]
+            assert ti[q, :ci[q]].tolist() == [x for x, _, _ in want], (mode, q)
     with pytest.raises(hx.HxError):
         ix.serialize_pages()
     ix.close()
