@@ -1,4 +1,5 @@
-"""sparsevec on the engine: build + scan timing on one MI355X (lock-step driver over the merge-join kernels of csrc/hx_sparse.hip).
+"""sparsevec on the engine: build + scan timing on one MI355X (round 3: searches and scans in the traversal kernel, hx_fused_sparse.hip; select and back-links on the
+lock-step driver over the merge-join kernels of csrc/hx_sparse.hip).
 python tools/bench_sparse.py [rows] [dim] [max_nnz]"""
 import json, sys, time
 import numpy as np
@@ -38,4 +39,4 @@ for q in range(64):
     top = set(np.argsort(dq, kind="stable")[:k].tolist())
     hits += len(top & set(tids[q, :cnt[q]].tolist()))
 print(json.dumps({"rows": n, "dim": dim, "max_nnz": mx, "record_bytes": int(rec.shape[1]), "metric": "cosine (normalised, negative inner product)", "m": m, "ef_construction": efc,
-                  "build_sec": round(build, 2), "qps": round(nq / dt, 1), "ef_search": efs, "recall_at_10": round(hits / (64 * k), 4), "path": "lock-step driver, k_sparse_groups / k_sparse_pairs"}))
+                  "build_sec": round(build, 2), "qps": round(nq / dt, 1), "ef_search": efs, "recall_at_10": round(hits / (64 * k), 4), "path": "traversal kernel (k_fused<OpSparse>: scans, build searches); select + back-links: lock-step driver over k_sparse_pairs" if ix.fused_stats()["tasks"] else "lock-step driver, k_sparse_groups / k_sparse_pairs"}))
