@@ -204,7 +204,8 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     if (mode == 1) clds = std::max<uint32_t>(clds, (uint32_t)((nch_ * 1024 + ((size_t)ef + 2) * 8 + 7) / 8));   // (mode 3 has no select phase)
       // select scratch aliases C's LDS part
     if (dev && dev->d_wtab) clds = std::max<uint32_t>(clds, dev->wt_size);                     // so does the W table
-    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * ((size_t)ef + 2) + 64 + 64) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };   // f_worker's carve
+    const uint32_t wcap = ef + 2u + ((mode == 3 && dev && dev->d_skip) ? 254u : 0u);   // repair searches: room for 254 uncounted skip-set members in W, beyond that FS_OVERFLOW
+    auto lds_bytes = [&](uint32_t cc) { return ((size_t)cc + 2 * (size_t)wcap + 64 + 64) * 8 + (64 + 32 + 64) * 4 + nch_ * 1024 + (size_t)(disc_lds ? disc_lds + 64 + 160 + 32 : 0) * 8; };   // f_worker's carve
     const size_t lds = lds_bytes(clds);
     // residency: one wave per workgroup, LDS-limited
     const size_t waves_cap = 4u * (size_t)(mode == 2 ? FUSED_MINW_ITER : ins ? FUSED_MINW_INS : FUSED_MINW);   // register-file limit: launch_bounds waves per SIMD x 4 SIMDs
@@ -267,7 +268,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     const size_t out_n = dev ? 0 : !ins ? (size_t)ntasks * k : (size_t)ntasks * FUSED_MAXL * 2 * mr.m;      // mode 2: k = limit
     const size_t cnt_n = dev ? 0 : !ins ? (size_t)ntasks : (size_t)ntasks * FUSED_MAXL;
     // device task/in/out buffers (one allocation, reused)
-    const size_t need = al16((size_t)ntasks * 4) * 5 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
+    const size_t need = al16((size_t)ntasks * 4) * 6 + al16(out_n * 4) * 3 + al16(cnt_n * 4) + 256;
     if (need > io.cap_io) {
         if (io.d_io) (void)hipFree(io.d_io);
         if (io.h_io) (void)hipHostFree(io.h_io);
@@ -283,6 +284,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     const size_t o_lv = o; o += al16((size_t)ntasks * 4);
     const size_t o_slot = o; o += al16((size_t)ntasks * 4);
     const size_t o_prob = o; o += al16((size_t)ntasks * 4);
+    const size_t o_ent = o; o += al16((size_t)ntasks * 4);
     const size_t in_bytes = o;
     const size_t o_st = o; o += al16((size_t)ntasks * 4);
     const size_t o_cnt = o; o += al16(cnt_n * 4);
@@ -294,6 +296,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     if (t_level) memcpy(io.h_io + o_lv, t_level, (size_t)ntasks * 4); else memset(io.h_io + o_lv, 0, (size_t)ntasks * 4);
     if (dev && dev->h_slots) memcpy(io.h_io + o_slot, dev->h_slots, (size_t)ntasks * 4);
     if (mode == 3) memcpy(io.h_io + o_prob, dev->h_prob, (size_t)ntasks * 4);
+    if (mode == 3 && dev->h_entry) memcpy(io.h_io + o_ent, dev->h_entry, (size_t)ntasks * 4);
     HX_HIP(this, hipMemcpyAsync(io.d_io, io.h_io, in_bytes, hipMemcpyHostToDevice, stream));
     FusedParams p;
     p.rows = d_rows; p.queries = d_queries; p.pitch = (uint32_t)pitch; p.nch = (uint32_t)((pitch + 1023) / 1024); p.n_rows = n_rows;
@@ -301,7 +304,7 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     p.l0_d = mr.d_l0_d; p.up_d = mr.d_up_d;
     p.m = mr.m; p.entry = entry; p.entry_level = entry_level;
     p.ntasks = ntasks; p.t_qsel = (const uint32_t *)(io.d_io + o_q); p.t_level = (const int32_t *)(io.d_io + o_lv);
-    p.ef = ef; p.k = k; p.ccap = ccap; p.clds = clds;
+    p.ef = ef; p.k = k; p.ccap = ccap; p.clds = clds; p.wcap = wcap;
     p.iter_mode = 0; p.limit = k; p.max_tuples = 0; p.emask = nullptr; p.disc = nullptr; p.disc_stride = 0; p.disc_lds = disc_lds; p.out_tix = (uint32_t *)(io.d_io + o_tix);
     if (mode == 2) { p.iter_mode = (uint32_t)it->iter_mode; p.max_tuples = it->max_tuples; p.emask = mr.d_emask; p.disc = (unsigned long long *)mr.d_disc; p.disc_stride = (uint32_t)disc_stride; }
     p.spill = (uint2 *)spill_ptr; p.spill_stride = ccap;
@@ -315,8 +318,10 @@ int hx_engine::fused_launch(HxFusedIo &io, int mode, uint32_t ntasks, const uint
     p.o_cst = FUSED_MAXL; p.o_lst = FUSED_MAXL * 2 * mr.m; p.t_oslot = nullptr;
     p.wtab = nullptr; p.wt_size = 0; p.wt_slot0 = 0; p.wt_valid = nullptr;
     p.sparse_cap = dtype == HX_SPARSE ? (uint32_t)std::min(dim, HX_SPARSE_MAX_NNZ) : 0u;
+    p.t_entry = (mode == 3 && dev && dev->h_entry) ? (const uint32_t *)(io.d_io + o_ent) : nullptr; p.skip = (mode == 3 && dev) ? dev->d_skip : nullptr;
     p.wl_out = nullptr; p.wl_cnt = nullptr; p.t_prob = nullptr; p.ondisk = (mode == 3 && dev && dev->ondisk) ? 1u : 0u;
-    if (mode == 3) { p.wl_out = (uint2 *)dev->d_wl_out; p.wl_cnt = dev->d_wl_cnt; p.t_prob = (const uint32_t *)(io.d_io + o_prob); }
+    p.wcap_out = ef;
+    if (mode == 3) { p.wl_out = (uint2 *)dev->d_wl_out; p.wl_cnt = dev->d_wl_cnt; p.t_prob = (const uint32_t *)(io.d_io + o_prob); if (dev->d_skip) p.wcap_out = wcap; }
     if (dev && dev->d_wtab) { p.wtab = (uint2 *)dev->d_wtab; p.wt_size = dev->wt_size; p.wt_slot0 = dev->wt_slot0; p.wt_valid = dev->d_wt_valid; }
     if (dev) {   // record = cnt[FUSED_MAXL] | ids[FUSED_MAXL][2m] | d[FUSED_MAXL][2m]  (hx_batch.hip reads the same layout)
         p.out_cnt = dev->d_rec; p.out_ids = dev->d_rec + FUSED_MAXL; p.out_d = (float *)(dev->d_rec + FUSED_MAXL + FUSED_MAXL * 2 * mr.m);

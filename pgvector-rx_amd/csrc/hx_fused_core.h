@@ -45,6 +45,7 @@ struct FusedParams {
     uint32_t m, entry; int32_t entry_level;
     uint32_t ntasks; const uint32_t *t_qsel; const int32_t *t_level;
     uint32_t ef, k, ccap, clds;                  // ccap: capacity of the candidate heap, its first clds entries in LDS
+    uint32_t wcap;                               // entries of the W heap and of the sorted-result array in LDS: ef + 2, more for repair searches (skip-set members are not counted, so W outgrows ef)
     uint2 *spill; uint32_t spill_stride;         // per-workgroup spill area of the candidate heap (entries)
     uint32_t *vis; uint64_t vis_words;            // per-workgroup visited set: open-addressing table of vis_words (power of 2) row ids
     uint32_t *next_task;
@@ -54,9 +55,12 @@ struct FusedParams {
     uint2 *wtab; uint32_t wt_size, wt_slot0; uint8_t *wt_valid;   // MODE 1: the layer-0 result set W of task t as an open-addressing table of wt_size {d, id} entries at
                                                   // wtab + (wt_slot0 + s) * wt_size (the back-link kernels look d(new row, x) up there instead of streaming row x); nullptr: off
     // MODE 3 (insert, search only: select_neighbors runs on the matrix cores afterwards, hx_mfma.hip): the sorted result set W of layer lc of task t goes to
-    // problem t_prob[t] + lc: wl_out[problem * ef + i] = {distance bits, id}, wl_cnt[problem] = |W|
-    uint2 *wl_out; uint32_t *wl_cnt; const uint32_t *t_prob;
+    // problem t_prob[t] + lc: wl_out[problem * wcap_out + i] = {distance bits, id}, wl_cnt[problem] = |W| (wcap_out = ef; wcap for repair searches)
+    uint2 *wl_out; uint32_t *wl_cnt; const uint32_t *t_prob; uint32_t wcap_out;
     uint32_t sparse_cap;                          // sparsevec (OpSparse): index / value slots per row record
+    // MODE 3 for vacuum's repair_graph_element (vacuum.rs:288-407): per task its own entry point (nullptr: entry / entry_level above) and the skip set --
+    // elements with skip[e] != 0 and the repaired element itself are traversed but not counted into the result set (scan.rs:330-336, 416-419)
+    const uint32_t *t_entry; const uint8_t *skip;
     uint32_t ondisk;                              // MODE 3 for aminsert: search_layer_disk semantics (W handed out nearest LAST, as scan.rs:441-446 sorts it)
     unsigned long long *n_dist;                   // [0] query-vs-row distances, [1] select distances, [2] max |C| seen
     // iterative scan (k_fused MODE 2): hnsw.iterative_scan relaxed_order (1) / strict_order (2), scan.rs:794-875
@@ -318,6 +322,7 @@ struct FusedCtx {
     FRows fr;
     uint2 *C, *W, *EP, *RES, *RL, *DL; uint32_t *IDS, *CTL; lds_u8 *QV, *EV; HStore CH, WH;
     uint32_t *vis; uint32_t lane; uint32_t status;
+    const uint8_t *skip; uint32_t skip_self;                                        // MODE 3 repair searches (nullptr: no skip set)
     GStore DS; lds_uint2 *DP, *WS; uint32_t *LV; uint32_t dlen, vcount;           // iterative scan: `discarded` min-heap, visited ids so far (the set survives resumes)
     unsigned long long nd0, nd1; uint32_t cmax;
     uint32_t tph[14];  // [13] select phase; diagnostic phase clocks (HX_F_DBG & 4): pop, list fetch, visited, compaction, distances, settle+prefilter, replay; [7] expansions, [8] heap pushes

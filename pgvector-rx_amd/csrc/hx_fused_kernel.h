@@ -9,7 +9,7 @@
 // ITER: search_layer_disk WITH the iterative scan's state (scan.rs:302-448): the visited set is the caller's and survives
 // resumes (fresh == false keeps it; eps_visited == false: resume_scan_items' entry points are already in it), and every
 // visited element that does not end in W goes to the `discarded` min-heap, in the reference's order of pushes.
-template <class OP, int LPR, bool ITER = false>
+template <class OP, int LPR, bool ITER = false, bool SKIP = false>
 __device__ __forceinline__ void f_search_layer(KParams &p_in, FusedCtx &cx, uint32_t n_ep, uint32_t ef, int layer, bool scan, bool fresh = true, bool eps_visited = true)
 {
     KParams &p = f_params_here(p_in);
@@ -129,12 +129,18 @@ __device__ __forceinline__ void f_search_layer(KParams &p_in, FusedCtx &cx, uint
         const uint2 c = cx.RES[0]; F_BAR();
         return c;
     };
+    // SKIP (vacuum's repair searches): members of the skip set are traversed but not counted (`should_count`, scan.rs:330-336, 416-419)
+    auto counted = [&](uint32_t id) -> bool {
+        if constexpr (!SKIP) return true;
+        else return cx.skip == nullptr || !(id == cx.skip_self || cx.skip[id] != 0);
+    };
     for (uint32_t i = 0; i < n_ep; i++) {
         if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
         const uint2 it = cx.EP[i];
+        if (SKIP && wl + 1u >= p.wcap) { cx.status = FS_OVERFLOW; break; }          // uncounted members made W outgrow its LDS array: the lock-step driver takes the task
         c_push(it); PHeap<false>::push(WA, wl, it, lane);
+        if (counted(it.y)) rlen++;
     }
-    rlen = wl;
     F_BAR();
     const uint32_t bmask = (uint32_t)(vis_words >> 2) - 1u;
     const bool ahead = layer == 0 && (p.fdbg & 8u);
@@ -239,7 +245,9 @@ __device__ __forceinline__ void f_search_layer(KParams &p_in, FusedCtx &cx, uint
                 else { const double f = wl ? (double)wtop : 1.7976931348623157e+308; add = !(!always_add && (double)d >= f); }
                 if (!add) { if (ITER) { d_push(it); if (cx.status != FS_OK) break; } continue; }   // scan.rs:385-404
                 if (clen >= p.ccap) { cx.status = FS_OVERFLOW; break; }
-                c_push(it); PHeap<false>::push(WA, wl, it, lane); rlen++;
+                if (SKIP && wl + 1u >= p.wcap) { cx.status = FS_OVERFLOW; break; }
+                c_push(it); PHeap<false>::push(WA, wl, it, lane);
+                if (counted(it.y)) rlen++;
                 if (tm) cx.tph[8]++;
                 if (clen > cx.cmax) cx.cmax = clen;
                 if (rlen > ef) {
@@ -437,7 +445,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
     constexpr bool INS = MODE == 1 || MODE == 3;           // find_element_neighbors; MODE 3 stops after each layer's search (select on the matrix cores)
     const uint32_t lm0 = 2u * p.m;
     // LDS carve, fixed-size regions first so that their addresses are compile-time constants (no scalar register holds them):
-    //   IDS[64] u32 | CTL[32] u32 | dsc[64] f32 | RES[64] | RL[64] | QV[nch KiB] | W[ef+2] | EP[ef+2] | C[clds] | MODE 2: DP[64] WS[160] LV[32] DS[disc_lds]
+    //   IDS[64] u32 | CTL[32] u32 | dsc[64] f32 | RES[64] | RL[64] | QV[nch KiB] | W[wcap] | EP[wcap] | C[clds] | MODE 2: DP[64] WS[160] LV[32] DS[disc_lds]   (wcap = ef + 2, more for repair searches)
     // (8-byte entries unless noted; hx_fused.inc.h sizes the allocation).  The select phase runs after the layer's search is over, so its scratch
     // (the candidate under test EV and the discarded list DL) reuses C.
     cx.IDS = (uint32_t *)lds;
@@ -447,8 +455,8 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
     cx.RL = cx.RES + 64;
     cx.QV = (lds_u8 *)(cx.RL + 64);                       // query parked in LDS (nch KiB)
     cx.W = (uint2 *)(cx.QV + p.nch * 1024u);
-    cx.EP = cx.W + (p.ef + 2);
-    cx.C = cx.EP + (p.ef + 2);
+    cx.EP = cx.W + p.wcap;
+    cx.C = cx.EP + p.wcap;
     cx.DP = (lds_uint2 *)(cx.C + p.clds);                 // MODE 2: queue of pending `discarded` pushes (64 entries), then the heap's LDS head
     cx.WS = cx.DP + 64; cx.LV = (uint32_t *)(cx.WS + 160);   // working set of a flush (<= 2*64 + depth entries), per-level {first index, offset}
     cx.DS.A = cx.WS + 160 + 32; cx.DS.L = MODE == 2 ? p.disc_lds : 0u;   // MODE 2: LDS head of the `discarded` heap
@@ -482,11 +490,14 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
         if (INS && new_level >= FUSED_MAXL) { if (lane == 0) p.status[t] = FS_HOST; continue; }
 
         // d(q, entry point): mod.rs:371-377 / scan.rs:475
-        if (lane == 0) cx.IDS[0] = p.entry;
+        const uint32_t entry = (MODE == 3 && p.t_entry) ? p.t_entry[t] : p.entry;
+        const int entry_level = (MODE == 3 && p.t_entry) ? p.level[entry] : p.entry_level;
+        cx.skip = MODE == 3 ? p.skip : nullptr; cx.skip_self = qsel;               // the repaired element is its own query row (vacuum.rs:331-333)
+        if (lane == 0) cx.IDS[0] = entry;
         F_BAR();
         const float d0 = f_dist<OP, LPR>(cx, cx.QV, cx.IDS, 1, lane);
         cx.nd0 += 1;
-        if (lane == 0) cx.EP[0] = fh_pack(d0, p.entry);
+        if (lane == 0) cx.EP[0] = fh_pack(d0, entry);
         F_BAR();
         uint32_t n_ep = 1;
 
@@ -495,7 +506,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
         // search_layer_disk's semantics (f64 comparisons, results nearest LAST, that order as the next layer's entry points): scans, and MODE 3 when it
         // serves aminsert's find_element_neighbors_on_disk (insert.rs:1021-1123; p.ondisk) instead of the build's find_element_neighbors
         const bool scan_sem = !INS || (MODE == 3 && p.ondisk != 0u);
-        for (int lc = p.entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
+        for (int lc = entry_level; lc > stop_above && cx.status == FS_OK; lc--) {
 #ifdef HX_EXPERIMENTS
             if constexpr (SA) {
                 f_search_layer_sa<OP, LPR>(p, cx, n_ep, 1u, lc);
@@ -504,7 +515,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
                 continue;
             }
 #endif
-            f_search_layer<OP, LPR, false>(p, cx, n_ep, 1u, lc, scan_sem);
+            f_search_layer<OP, LPR, false, MODE == 3>(p, cx, n_ep, 1u, lc, scan_sem);
             const uint32_t wl = cx.CTL[1];
             if (wl > 0) {
                 f_sort_results(cx, wl, scan_sem);
@@ -595,12 +606,12 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
             }
             if (lane == 0) { p.out_cnt[t] = cnt; p.status[t] = cx.status; }
         } else {
-            const int start = new_level < p.entry_level ? new_level : p.entry_level;
+            const int start = new_level < entry_level ? new_level : entry_level;
             const size_t obase = (size_t)os * p.o_cst;
             for (uint32_t i = lane; i < FUSED_MAXL; i += 64) p.out_cnt[obase + i] = 0;
             KParams &p_task = p;
             for (int lc = start; lc >= 0 && cx.status == FS_OK; lc--) {
-                f_search_layer<OP, LPR, false>(p_task, cx, n_ep, p_task.ef, lc, scan_sem);   // mod.rs:407-416 / insert.rs:1088-1101
+                f_search_layer<OP, LPR, false, MODE == 3>(p_task, cx, n_ep, p_task.ef, lc, scan_sem);   // mod.rs:407-416 / insert.rs:1088-1101
                 if (cx.status != FS_OK) break;
                 KParams &p = f_params_here(p_task);            // the select phase derives its own view of the parameters (dead again when the layer is done)
                 const uint32_t lm = lc == 0 ? lm0 : p.m;
@@ -627,7 +638,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
                 }
                 if constexpr (MODE == 3) {                                           // W (ascending) leaves the kernel; select_neighbors follows in hx_mfma.hip
                     const size_t pr = (size_t)p.t_prob[t] + (size_t)lc;
-                    uint2 *dst = p.wl_out + pr * p.ef;
+                    uint2 *dst = p.wl_out + pr * p.wcap_out;
                     for (uint32_t i = lane; i < wl; i += 64) dst[i] = cx.EP[i];
                     if (lane == 0) p.wl_cnt[pr] = wl;
                     F_BAR();

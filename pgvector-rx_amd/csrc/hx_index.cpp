@@ -2053,7 +2053,78 @@ int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uin
     uint64_t n_rep = 0;
     auto &dts = ix->disk_pool;
     // repairs `elems` (each against `entries[i]`) in lock-step, then overwrites their neighbour tuples (vacuum.rs:288-407)
-    auto repair = [&](const std::vector<uint32_t> &elems, const std::vector<int64_t> &entries) -> int {
+    // Device placement of the repair searches (round 3): k_fused MODE 3 with search_layer_disk's semantics, the skip set (the dead elements + the repaired
+    // element itself: traversed, not counted, not selected; ef_construction + 1) and a per-task entry point; the lm nearest of every layer's W that are
+    // not in the skip set become the element's new lists.  Used while the index holds no element deleted by an EARLIER vacuum (load_element would skip
+    // those; they are unlinked, but the lock-step driver keeps the letter of scan.rs:178-181), for rows the kernel serves and m <= 32.
+    const bool dev_repair = ix->fused_scan_ok() && 2 * g.m <= 64 && std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) == g.deleted.end();
+    uint8_t *d_skip = nullptr;
+    struct SkipFree { uint8_t *&p; ~SkipFree() { if (p) (void)hipFree(p); } } skip_free{d_skip};
+    if (dev_repair && n) {
+        if (hipSetDevice(ix->e->device) != hipSuccess || hipMalloc((void **)&d_skip, n) != hipSuccess ||
+            hipMemcpy(d_skip, del.data(), n, hipMemcpyHostToDevice) != hipSuccess) return ix->fail(HX_E_HIP, "vacuum: uploading the skip set failed");
+    }
+    auto repair_on_device = [&](const std::vector<uint32_t> &elems, const std::vector<int64_t> &entries, std::vector<uint32_t> &left, std::vector<int64_t> &left_ent) -> int {
+        std::vector<uint32_t> who, qsel, prob, h_entry; std::vector<int32_t> tl;
+        uint32_t P = 0;
+        for (size_t i = 0; i < elems.size(); i++) {
+            if (entries[i] < 0 || (int64_t)elems[i] == entries[i]) continue;       // vacuum.rs:300-303
+            const uint32_t e = elems[i], ent = (uint32_t)entries[i];
+            if (g.deleted[ent]) {                                                   // load_element(entry) -> None: every list comes out empty (insert.rs:1037-1048)
+                for (int lc = 0; lc <= g.level[e]; lc++) g.cnt(e, lc) = 0;
+                ix->mark_dirty(e); n_rep++;
+                continue;
+            }
+            who.push_back(e); qsel.push_back(e); tl.push_back(g.level[e]); h_entry.push_back(ent); prob.push_back(P);
+            P += (uint32_t)std::min(g.level[e], g.level[ent]) + 1u;
+        }
+        if (who.empty()) return HX_OK;
+        int r = ix->sync_mirror();
+        if (r) return r;
+        hx_engine *en = ix->e;
+        const uint32_t nt = (uint32_t)who.size(), ef = (uint32_t)ix->efc + 1u, wst = ef + 2u + 254u;     // insert.rs:1081-1086; wst: the W lists' stride (hx_fused.inc.h: wcap of a repair launch)
+        if ((r = en->wsel_reserve(P, wst)) || (r = en->db_reserve_records(nt))) return ix->fail(r, en->err);
+        HxWselWork &w = en->wsel;
+        if (hipMemsetAsync(w.d_cnt, 0, (size_t)P * 4, en->stream) != hipSuccess) return ix->fail(HX_E_HIP, "vacuum: clearing the W counts failed");
+        HxFusedDev dev; dev.d_rec = en->bw.d_rec; dev.rec_words = hx_rec_words((uint32_t)g.m); dev.h_slots = nullptr;
+        dev.d_wl_out = w.d_wl; dev.d_wl_cnt = w.d_cnt; dev.h_prob = prob.data(); dev.ondisk = true; dev.h_entry = h_entry.data(); dev.d_skip = d_skip;
+        std::vector<uint32_t> tstat(nt); uint64_t cnts[2] = {0, 0};
+        if ((r = en->fused_run(3, nt, qsel.data(), tl.data(), ef, 0, (uint32_t)h_entry[0], g.level[h_entry[0]],
+                               nullptr, nullptr, nullptr, tstat.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(r, en->err);
+        ix->counters[4] += cnts[0];
+        std::vector<uint32_t> wcnt(P); std::vector<uint2> wl((size_t)P * wst);
+        if (hipMemcpyAsync(wcnt.data(), w.d_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, en->stream) != hipSuccess ||
+            hipMemcpyAsync(wl.data(), w.d_wl, (size_t)P * wst * 8, hipMemcpyDeviceToHost, en->stream) != hipSuccess ||
+            hipStreamSynchronize(en->stream) != hipSuccess) return ix->fail(HX_E_HIP, "vacuum: reading the W lists failed");
+        for (uint32_t k = 0; k < nt; k++) {
+            const uint32_t e = who[k];
+            if (tstat[k] != 0) { left.push_back(e); left_ent.push_back((int64_t)h_entry[k]); continue; }   // outgrew its tables: the lock-step driver
+            const int start = std::min(g.level[e], g.level[h_entry[k]]);
+            for (int lc = 0; lc <= g.level[e]; lc++) {
+                Cand *lst = g.list(e, lc); size_t c = 0; const size_t lm = (size_t)g.lm(lc);
+                if (lc <= start) {
+                    const size_t pr = (size_t)prob[k] + (size_t)lc; const uint2 *W = wl.data() + pr * wst;   // nearest LAST
+                    for (size_t j = wcnt[pr]; j-- > 0 && c < lm;) {                  // filtered.iter().rev().take(lm), insert.rs:1103-1117
+                        if (W[j].y == e || del[W[j].y]) continue;
+                        memcpy(&lst[c].d, &W[j].x, 4); lst[c].id = W[j].y; c++;
+                    }
+                }
+                g.cnt(e, lc) = (uint16_t)c;
+            }
+            ix->mark_dirty(e); n_rep++;
+        }
+        ix->fused_tasks += nt; ix->fused_redo += left.size();
+        return HX_OK;
+    };
+    auto repair = [&](const std::vector<uint32_t> &elems_in, const std::vector<int64_t> &entries_in) -> int {
+        std::vector<uint32_t> elems_l; std::vector<int64_t> entries_l;
+        if (dev_repair) {
+            int r0 = repair_on_device(elems_in, entries_in, elems_l, entries_l);
+            if (r0) return r0;
+            if (elems_l.empty()) return HX_OK;
+        }
+        const std::vector<uint32_t> &elems = dev_repair ? elems_l : elems_in;
+        const std::vector<int64_t> &entries = dev_repair ? entries_l : entries_in;
         std::vector<LsTask *> tasks; std::vector<uint32_t> who;
         while (dts.size() < elems.size()) dts.emplace_back(new DiskNeighborsTask());
         for (size_t i = 0; i < elems.size(); i++) {

@@ -81,7 +81,8 @@ struct HxMirror {
 struct HxFusedDev { uint32_t *d_rec = nullptr; uint32_t rec_words = 0; const uint32_t *h_slots = nullptr;
                     void *d_wtab = nullptr; uint32_t wt_size = 0, wt_slot0 = 0; uint8_t *d_wt_valid = nullptr;
                     // mode 3 (search only; hx_mfma.hip selects): layer lc of task t is problem h_prob[t] + lc; its W goes to d_wl_out[problem * ef ..], |W| to d_wl_cnt[problem]
-                    void *d_wl_out = nullptr; uint32_t *d_wl_cnt = nullptr; const uint32_t *h_prob = nullptr; bool ondisk = false; };   // ondisk: search_layer_disk semantics (aminsert)   // W tables of the members (hx_fused_core.h FusedParams::wtab)
+                    void *d_wl_out = nullptr; uint32_t *d_wl_cnt = nullptr; const uint32_t *h_prob = nullptr; bool ondisk = false;
+                    const uint32_t *h_entry = nullptr; const uint8_t *d_skip = nullptr; };   // mode 3 repair searches: per-task entry points (host array), skip flags per element (device)   // ondisk: search_layer_disk semantics (aminsert)   // W tables of the members (hx_fused_core.h FusedParams::wtab)
 
 // device-side grouping of a batch's back-link ops (hx_group.hip): workspace + the grouped arrays it leaves on the device
 struct HxGroupWork {

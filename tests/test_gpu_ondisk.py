@@ -87,7 +87,11 @@ def test_vacuum_identical_to_oracle(dtype, metric, dim, m, efc):
     e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, 64)
     dead = np.concatenate([np.arange(400, 1100), [3]]).astype(np.int64)      # tid 3 dies, tid 700 keeps element 3 alive
     dead = dead[dead != 700]
+    before = ix.fused_stats()["tasks"]
     nd, nr = ix.vacuum(dead, batch=1)
+    st = ix.fused_stats()
+    assert st["tasks"] - before > 0                               # repair searches ran in the traversal kernel (MODE 3 with the skip set), round 3
+    print("\nrepair searches on the device: %d, of which handed to the lock-step driver (W outgrew its LDS array): %d" % (st["tasks"] - before, st["redone"]))
     o.vacuum(dead)
     assert nd == sum(o.deleted(i) for i in range(n)) and nr > 0
     assert [ix.deleted(i) for i in range(n)] == [o.deleted(i) for i in range(n)]
