@@ -554,7 +554,7 @@ def run(a, json_fd):
         "fused": ix.fused_stats(),
         "parity": "graphs, top-k lists and iterative scans bit-identical to the CPU oracle run in the device's canonical summation order (ORC_ORDER_W64: tests/, -m gpu); "
                   "distances within 1e-5 * d (L2, L1) / 1e-5 * sum|a_i b_i| (inner product) of the reference's sequential f32 order; the build uses snapshot batches "
-                  "(insert_batch_cap), whose recall at this ef_search equals the reference's one-row-at-a-time schedule query by query at 100k and 300k x 768 "
+                  "(insert_batch_cap), whose recall at this ef_search equals the reference's one-row-at-a-time schedule query by query at 100k, 300k and 1M x 768 (the 1M fixture is this bench's own size and mixture) "
                   "(tests/test_gpu_recall_parity.py; searches starved to ef_search <= 20 lose up to 1.4 % at this cap, none at caps <= 4096: DESIGN.md 4)",
         "dist_backend": (comm.backend if comm is not None else None),
         "dist_build_stage_seconds_rank0": dist_stages,

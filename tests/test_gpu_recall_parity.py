@@ -1,4 +1,5 @@
-"""Recall parity of the batched device build against the REFERENCE schedule at a size where batching could matter.
+"""Recall parity of the batched device build against the REFERENCE schedule at a size where batching could matter (round 3: also at the bench's own size and
+mixture, tests/golden/recall_parity_1000k.json: 1M x 768, 1024 centres, 1.9 hours of one core for the sequential oracle build).
 
 tests/golden/recall_parity_100k.json and recall_parity_300k.json (45 minutes of one core) hold recall@10 of the oracle's strictly sequential build (one row at a time, the reference's own
 summation order) on 100 000 x vector(768) L2, m = 16, ef_construction = 200 -- BASELINE configs[1]'s shape; it was produced once on a CPU by
