@@ -1864,6 +1864,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
     if (2 * g.m > (int)HX_PAIR_MAX_ROWS) return ix->fail(HX_E_ARG, "the on-disk insert path serves m <= 32");
     if (batch == 0) batch = 1;
+    hx_index::Timer t_all(ix->prof[10]);
     int rc = ix->ensure_host_lists();
     if (rc) return rc;
     const int mxl = max_level_for(g.m);
@@ -1944,6 +1945,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
             }
         }
         // duplicate candidates: leading zero-distance layer-0 neighbours, compared byte for byte (find_duplicate_on_disk insert.rs:1180-1214)
+        const double t_2a = hx_index::now_s();
         std::vector<uint32_t> da, db; std::vector<uint32_t> dstart(b + 1, 0u);
         for (uint32_t i = 0; i < b; i++) {
             if (!nbs[i].empty()) for (const Cand &c : nbs[i][0]) { if (c.d != 0.0f) break; da.push_back(base + i); db.push_back(c.id); }
@@ -1982,6 +1984,8 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
         // stage 2b: get_update_index reads and write_neighbor_update writes ONE list (and row data, deleted flags and heap-TID counts, which the
         // back-connections do not change), so updates of different lists commute: the batch's updates run as waves -- wave k holds the k-th update of
         // every list, in member order per list -- one lock-step round per wave instead of one per member.  batch == 1 is the reference's order exactly.
+        ix->prof[8] += hx_index::now_s() - t_2a;
+        hx_index::Timer t_2b(ix->prof[9]);
         if (!ops.empty()) {
             std::vector<uint32_t> order(ops.size());
             for (uint32_t k = 0; k < ops.size(); k++) order[k] = k;
@@ -1994,7 +1998,49 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
                 runs.emplace_back(k, j); k = j;
             }
             auto &uts = ix->update_pool;
-            for (uint32_t wave = 0;; wave++) {
+            // Device placement of a wave (round 3): the host settles what needs no distance (insert.rs:524-527, 556-559, 566-625) and k_update_index
+            // (hx_links.hip) answers the full lists, one wavefront per op, from the list contents the host hands over.
+            const bool dev_upd = ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192;
+            std::vector<uint32_t> wops, devq; std::vector<int> wres;
+            for (uint32_t wave = 0; dev_upd; wave++) {
+                wops.clear(); devq.clear();
+                for (const auto &r : runs) if (r.first + wave < r.second) wops.push_back(order[r.first + wave]);
+                if (wops.empty()) break;
+                wres.assign(wops.size(), -4);                                        // -4: the device decides
+                for (size_t k = 0; k < wops.size(); k++) {
+                    const UOp &o = ops[wops[k]];
+                    const Cand *lst = g.list(o.nbr, o.layer); const size_t cnt = g.cnt(o.nbr, o.layer), lm = (size_t)g.lm(o.layer);
+                    if (g.deleted[o.nbr]) { wres[k] = -3; continue; }
+                    if (cnt < lm) { wres[k] = -2; continue; }
+                    for (size_t i = 0; i < cnt; i++) if (g.deleted[lst[i].id] || g.ntids[lst[i].id] == 0) { wres[k] = (int)i; break; }
+                    if (wres[k] == -4) devq.push_back((uint32_t)k);
+                }
+                if (!devq.empty()) {
+                    const uint32_t nd = (uint32_t)devq.size(), stride = 2u * (uint32_t)g.m;
+                    uint32_t *h_ids = nullptr, *h_cnt = nullptr; float *h_d = nullptr, *h_nd = nullptr;
+                    if ((rc = ix->e->update_index_stage(nd, stride, &h_ids, &h_d, &h_nd, &h_cnt))) return ix->fail(rc, ix->e->err);
+                    ix->pool->parallel_for((nd + 1023) / 1024, [&](size_t ci) {
+                        for (uint32_t j = (uint32_t)ci * 1024; j < std::min<uint32_t>(nd, (uint32_t)ci * 1024 + 1024); j++) {
+                            const UOp &o = ops[wops[devq[j]]];
+                            const Cand *lst = g.list(o.nbr, o.layer); const uint32_t cnt = g.cnt(o.nbr, o.layer);
+                            for (uint32_t i = 0; i < cnt; i++) { h_ids[(size_t)j * stride + i] = lst[i].id; h_d[(size_t)j * stride + i] = lst[i].d; }
+                            h_cnt[j] = cnt; h_nd[j] = o.d;
+                        }
+                    });
+                    const int32_t *slot = nullptr; uint64_t np = 0;
+                    const double t_k = hx_index::now_s();
+                    if ((rc = ix->e->update_index_run(&slot, &np))) return ix->fail(rc, ix->e->err);
+                    ix->prof[3] += hx_index::now_s() - t_k; ix->prof[5] += 1.0;
+                    ix->counters[3] += np;
+                    for (uint32_t j = 0; j < nd; j++) wres[devq[j]] = slot[j];
+                }
+                for (size_t k = 0; k < wops.size(); k++) {
+                    if (wres[k] == -3) continue;
+                    const UOp &o = ops[wops[k]];
+                    write_neighbor_update(ix, o.nbr, o.layer, o.id, o.d, wres[k]);
+                }
+            }
+            for (uint32_t wave = 0; !dev_upd; wave++) {
                 std::vector<LsTask *> utasks; std::vector<uint32_t> which;
                 for (const auto &r : runs) {
                     if (r.first + wave >= r.second) continue;

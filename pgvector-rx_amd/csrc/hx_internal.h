@@ -168,6 +168,10 @@ struct hx_engine {
     int db_apply(uint32_t base, uint32_t b, const uint32_t *d_rec, const uint8_t *h_dup, uint32_t rank, uint32_t world, uint32_t *n_ops_out);
     int db_import_lists(const uint32_t *d_xrec, uint32_t n_records);
     HxGroupWork grp;
+    // aminsert's get_update_index for one wave of full lists (hx_links.hip: k_update_index): stage -> fill the pinned arrays -> run
+    int update_index_stage(uint32_t n_ops, uint32_t stride, uint32_t **ids, float **d, float **new_d, uint32_t **cnt);
+    int update_index_run(const int32_t **slot_out, uint64_t *n_pairs);
+    size_t ui_o_nd = 0, ui_o_cnt = 0, ui_o_ids = 0, ui_o_d = 0, ui_o_slot = 0, ui_in = 0; uint32_t ui_n = 0, ui_stride = 0;
     int links_run(uint32_t n_groups, const uint32_t *target, const uint32_t *layer, const uint32_t *op_off,
                   const uint32_t *op_new, const float *op_d, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs,
                   bool want_lists = true);   // false: the updated lists stay in the mirror only (the host pulls them when it needs them)

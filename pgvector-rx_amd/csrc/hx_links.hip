@@ -564,6 +564,139 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
     if (lane == 0) atomicAdd(p.n_pairs, ndist);
 }
 
+// =================================================================================================
+// K4d k_update_index: get_update_index of aminsert (src/index/insert.rs:500-739) for FULL lists, one wavefront per (neighbour, layer, new element) op.
+//   Stateless: the host hands over the list as it stands (ids + the stored distances to the list's owner: the very bits insert.rs:606 recomputes) and
+//   d(owner, new element); the kernel answers the slot the new element takes (-3: none).  Candidates = the lm members, stable-sorted by distance, with
+//   the new element behind every member that is not farther (insert.rs:630-665: two stable sorts); the heuristic walks them (insert.rs:673-712): a
+//   member is kept when no already-kept MEMBER lies at least as close to it as the owner does (pairs with the new element are skipped, :680-693) --
+//   its row parked in LDS, the kept members' rows streamed FUSED_RB at a time with the reference's early exit (f_any_le) -- and pruned members fill
+//   the remaining places in order; the new element replaces the first member that is not kept (:722-737).  The pair distances are evaluated only
+//   when the walk asks for them (the lock-step driver orders all lm (lm - 1) / 2 up front); the answer is the same.
+// =================================================================================================
+struct UpdParams {
+    const uint8_t *rows; uint32_t pitch, n_ops, stride;
+    const uint32_t *ids; const float *d; const float *new_d; const uint32_t *cnt;
+    int32_t *slot; unsigned long long *n_pairs;
+};
+
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64, 4)
+k_update_index(const UpdParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *LID = (uint32_t *)lds; float *LD = (float *)(LID + 64);
+    uint32_t *ORD = (uint32_t *)(LD + 64);                      // sorted position -> slot; 64 = the new element  [<= 65 entries]
+    uint32_t *SEL = ORD + 72, *PRN = SEL + 64;                  // kept members' row ids (walk order); pruned members' slots
+    float *DSC = (float *)(PRN + 64);
+    lds_u8 *QV = (lds_u8 *)(DSC + 64);
+    const uint32_t lane = threadIdx.x, op = blockIdx.x;
+    if (op >= p.n_ops) return;
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC};
+    const uint32_t cnt = p.cnt[op], lm = cnt;                   // full list
+    const float nd = p.new_d[op];
+    float di = 0.0f;
+    if (lane < cnt) { LID[lane] = p.ids[(size_t)op * p.stride + lane]; di = p.d[(size_t)op * p.stride + lane]; LD[lane] = di; }
+    F_WSYNC();
+    uint32_t rank = 0;                                          // stable rank of member `lane` among the members
+    for (uint32_t j = 0; j < cnt; j++) { const float dj = LD[j]; rank += (dj < di || (dj == di && j < lane)) ? 1u : 0u; }
+    const uint32_t pn = (uint32_t)__popcll(__ballot(lane < cnt && !(di > nd)));   // the new element sorts behind every member with d <= new_d
+    if (lane < cnt) ORD[rank + (di > nd ? 1u : 0u)] = lane;
+    if (lane == 0) ORD[pn] = 64u;
+    F_WSYNC();
+    uint32_t nsel = 0, nselm = 0, npr = 0; bool new_sel = false, kept = false;
+    unsigned long long ndist = 0;
+    for (uint32_t h = 0; h <= cnt; h++) {
+        if (nsel >= lm) break;
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ORD[h]);
+        if (s == 64u) { new_sel = true; nsel++; continue; }
+        bool hit = false;
+        if (nselm) {
+            f_park_w(fp, p.rows + (size_t)LID[s] * p.pitch, lane, QV);
+            hit = f_any_le<OP, LPR>(fp, QV, SEL, nselm, lane, LD[s], ndist);
+        }
+        if (!hit) { if (lane == 0) SEL[nselm] = LID[s]; nselm++; nsel++; if (lane == s) kept = true; }
+        else { if (lane == 0) PRN[npr] = s; npr++; }
+        F_WSYNC();
+    }
+    for (uint32_t k = 0; k < npr && nsel < lm; k++, nsel++) if (lane == PRN[k]) kept = true;   // insert.rs:707-712
+    int res = -3;
+    if (new_sel) { const unsigned long long out = __ballot(lane < cnt && !kept); if (out) res = (int)__builtin_ctzll(out); }
+    if (lane == 0) { p.slot[op] = res; atomicAdd(p.n_pairs, ndist); }
+}
+
+template <class OP>
+static hipError_t launch_update_index(hx_engine *e, const UpdParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (64 * 5 + 72) * 4 + nch * 1024;
+    if (e->pitch <= 128) hipLaunchKernelGGL((k_update_index<OP, 8>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
+    else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_index<OP, 32>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
+    else hipLaunchKernelGGL((k_update_index<OP, 64>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
+    return hipGetLastError();
+}
+
+// staging of one wave of get_update_index ops: pinned arrays the caller fills (ids / d: `stride` entries per op), then update_index_run
+int hx_engine::update_index_stage(uint32_t n_ops, uint32_t stride, uint32_t **ids, float **d, float **new_d, uint32_t **cnt)
+{
+    HxMirror &mr = mirror;
+    if (n_ops == 0 || stride == 0 || stride > 64) return fail(HX_E_ARG, "update_index_stage: bad sizes");
+    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_update_index serves dense rows <= 8 KiB");
+    HX_HIP(this, hipSetDevice(device));
+    size_t o = 64;
+    ui_o_nd = o; o += al16((size_t)n_ops * 4);
+    ui_o_cnt = o; o += al16((size_t)n_ops * 4);
+    ui_o_ids = o; o += al16((size_t)n_ops * stride * 4);
+    ui_o_d = o; o += al16((size_t)n_ops * stride * 4);
+    ui_in = o;
+    ui_o_slot = o; o += al16((size_t)n_ops * 4);
+    if (o > mr.cap_lk) {
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (mr.h_lk) (void)hipHostFree(mr.h_lk);
+        if (mr.d_lk) (void)hipFree(mr.d_lk);
+        mr.h_lk = mr.d_lk = nullptr; mr.cap_lk = 0;
+        const size_t n = o * 2;
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_lk, n, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&mr.d_lk, n));
+        mr.cap_lk = n;
+    }
+    uint8_t *h = mr.h_lk;
+    memset(h, 0, 64);
+    *new_d = (float *)(h + ui_o_nd); *cnt = (uint32_t *)(h + ui_o_cnt); *ids = (uint32_t *)(h + ui_o_ids); *d = (float *)(h + ui_o_d);
+    ui_n = n_ops; ui_stride = stride;
+    return HX_OK;
+}
+
+int hx_engine::update_index_run(const int32_t **slot_out, uint64_t *n_pairs)
+{
+    HxMirror &mr = mirror;
+    if (ui_n == 0) return fail(HX_E_STATE, "update_index_run without update_index_stage");
+    HX_HIP(this, hipSetDevice(device));
+    HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, ui_in, hipMemcpyHostToDevice, stream));
+    UpdParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.n_ops = ui_n; p.stride = ui_stride;
+    p.ids = (const uint32_t *)(mr.d_lk + ui_o_ids); p.d = (const float *)(mr.d_lk + ui_o_d); p.new_d = (const float *)(mr.d_lk + ui_o_nd);
+    p.cnt = (const uint32_t *)(mr.d_lk + ui_o_cnt); p.slot = (int32_t *)(mr.d_lk + ui_o_slot); p.n_pairs = (unsigned long long *)mr.d_lk;
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_update_index<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_update_index<OpF16<K>>(this, p)
+    HX_DISPATCH(this, F32C, F16C, ls = launch_update_index<OpHamming>(this, p), ls = launch_update_index<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+    HX_HIP(this, ls);
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk, mr.d_lk, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk + ui_o_slot, mr.d_lk + ui_o_slot, (size_t)ui_n * 4, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    unsigned long long np; memcpy(&np, mr.h_lk, 8);
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    *slot_out = (const int32_t *)(mr.h_lk + ui_o_slot);
+    ui_n = 0;
+    return HX_OK;
+}
+
 template <class OP, int LPR, int SLOTS>
 static hipError_t launch_links_cached_s(hx_engine *e, const LinksParams &p)
 {

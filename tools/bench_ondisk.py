@@ -25,5 +25,7 @@ for b in (10, 256, 2048, 8192):
     t0 = time.perf_counter(); ix.insert_ondisk(base + b, levels[base + b:base + b + k], tids=np.arange(base + b, base + b + k), batch=b); dt = time.perf_counter() - t0
     pr = ix.profile()
     print(json.dumps({"base_rows": base, "dim": dim, "m": m, "ef_construction": efc, "concurrent_inserts": b, "rows": k, "rows_per_s": round(k / dt, 1),
-                      "lock_step_rounds": pr["rounds"], "fused_s": round(pr["fused_s"], 4), "round_s": round(pr["round_s"], 4), "advance_s": round(pr["advance_s"], 4)}), flush=True)
+                      "lock_step_rounds": pr["rounds"], "fused_s": round(pr["fused_s"], 4), "round_s": round(pr["round_s"], 4), "advance_s": round(pr["advance_s"], 4),
+                      "mirror_sync_s": round(pr["mirror_sync_s"], 4), "members_s": round(pr["links_setup_s"], 4), "updates_s": round(pr["links_lockstep_s"], 4),
+                      "total_s": round(pr["insert_total_s"], 4)}), flush=True)
     ix.close(); e.close(); del rows
