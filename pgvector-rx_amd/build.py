@@ -19,6 +19,7 @@ SOURCES = {
     "hx_fused_bit.hip": ["hx_ops.h", "hx_fused_core.h", "hx_fused_kernel.h"],
     "hx_fused_sparse.hip": ["hx_ops.h", "hx_fused_core.h", "hx_fused_kernel.h"],
     "hx_links.hip": ["hx_ops.h", "hx_fused_core.h"],
+    "hx_biglist.hip": ["hx_ops.h", "hx_fused_core.h"],
     "hx_mfma.hip": ["hx_ops.h"],
     "hx_sparse.hip": ["hx_ops.h"],
     "hx_group.hip": [],

@@ -1,0 +1,254 @@
+// hx_biglist.hip -- select_neighbors (graph/mod.rs:269-339) and update_neighbor_connections (mod.rs:442-489) for lists of ANY legal size
+// (options.rs:203-225: m <= 100, so layer-0 lists of up to 200 and result sets W of up to ef_construction <= 1000 candidates).  The kernels of
+// hx_links.hip keep a list in one wavefront's lanes and its pair matrix in LDS (m <= 32); here a list lives in LDS arrays walked 64 entries at a
+// time and no pair matrix is formed at all: a candidate's row is parked in LDS and the rows selected so far are streamed past it with the
+// reference's early exit (f_any_le: FUSED_RB rows per memory round trip), i.e. exactly the distance evaluations check_element_closer makes, in
+// its order, a few rows further at most.  Stateless: the host hands the lists over as they stand and takes the new ones back (it is the master
+// copy for these index shapes); distances are the canonical ones, so lists and distance bits equal the lock-step driver's and the oracle's.
+//   k_select_w   one wavefront per (new element, layer): select_neighbors over the result set W the traversal kernel (MODE 3) left on the device
+//   k_list_ops   one wavefront per (neighbour, layer) list: its back-links of the batch applied in insertion order
+#include "hx_fused_core.h"
+
+#define BL_MAX 208            /* lm <= 200, + the new element, rounded up */
+
+// select_neighbors over n candidates in ascending order (cid(h), cd(h)); RI[0..return) = positions h of the new list, in its order
+template <class OP, int LPR, class IDF, class DF>
+__device__ __forceinline__ uint32_t bl_select(const FRows &fp, lds_u8 *QV, uint32_t *SEL, uint32_t *RI, uint32_t *DI, const uint32_t n, const uint32_t maxn,
+                                              IDF cid, DF cd, const uint32_t lane, unsigned long long &ndist)
+{
+    if (n <= maxn) {                                                                // mod.rs:276-278
+        for (uint32_t i = lane; i < n; i += 64) RI[i] = i;
+        F_WSYNC();
+        return n;
+    }
+    uint32_t nR = 0, nD = 0;
+    for (uint32_t h = 0; h < n; h++) {
+        if (nR >= maxn) break;                                                      // mod.rs:285-287
+        const uint32_t id = (uint32_t)__builtin_amdgcn_readfirstlane((int)cid(h));
+        bool closer = true;                                                         // check_element_closer, mod.rs:315-339
+        if (nR) {
+            f_park_w(fp, fp.rows + (size_t)id * fp.pitch, lane, QV);
+            closer = !f_any_le<OP, LPR>(fp, QV, SEL, nR, lane, cd(h), ndist);
+        }
+        if (lane == 0) { if (closer) { SEL[nR] = id; RI[nR] = h; } else DI[nD] = h; }
+        if (closer) nR++; else nD++;
+        F_WSYNC();
+    }
+    for (uint32_t k = 0; k < nD && nR < maxn; k++, nR++) if (lane == 0) RI[nR] = DI[k];   // mod.rs:300-305
+    F_WSYNC();
+    return nR;
+}
+
+struct SelWParams {
+    const uint8_t *rows; uint32_t pitch, cap, n_prob, stride, lm0;                 // cap: 0 (dense rows only -- sparsevec lists stay on the lock-step driver's merge-join pair kernels, which measured faster: one lane per row leaves a one-wave-per-list kernel mostly idle)
+    const uint2 *wl; const uint32_t *wl_cnt, *lm;                                   // W of problem pr: wl[pr * stride ..), ascending, {distance bits, id}
+    uint32_t *out_ids; float *out_d; uint32_t *out_cnt; unsigned long long *n_pairs;
+};
+
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64, 4)
+k_select_w(const SelWParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *SEL = (uint32_t *)lds, *RI = SEL + BL_MAX, *DI = RI + BL_MAX;        // DI: stride entries
+    float *DSC = (float *)(DI + ((p.stride + 15u) & ~15u));
+    lds_u8 *QV = (lds_u8 *)(DSC + 64);
+    const uint32_t lane = threadIdx.x, pr = blockIdx.x;
+    if (pr >= p.n_prob) return;
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC, p.cap};
+    const uint2 *W = p.wl + (size_t)pr * p.stride;
+    const uint32_t n = p.wl_cnt[pr] < p.stride ? p.wl_cnt[pr] : p.stride, lm = p.lm[pr];
+    unsigned long long ndist = 0;
+    const uint32_t nR = bl_select<OP, LPR>(fp, QV, SEL, RI, DI, n, lm,
+                                           [&](uint32_t h) { return W[h].y; }, [&](uint32_t h) { return __builtin_bit_cast(float, W[h].x); }, lane, ndist);
+    for (uint32_t i = lane; i < nR; i += 64) {
+        const uint2 c = W[RI[i]];
+        p.out_ids[(size_t)pr * p.lm0 + i] = c.y; p.out_d[(size_t)pr * p.lm0 + i] = __builtin_bit_cast(float, c.x);
+    }
+    if (lane == 0) { p.out_cnt[pr] = nR; atomicAdd(p.n_pairs, ndist); }
+}
+
+struct ListOpsParams {
+    const uint8_t *rows; uint32_t pitch, cap, n_groups, lm0;
+    uint32_t *ids; float *d; uint32_t *cnt;                                         // list of group g: ids/d[g * lm0 ..), cnt[g]  (in and out)
+    const uint32_t *lm, *op_off, *op_new; const float *op_d; unsigned long long *n_pairs;
+};
+
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64, 4)
+k_list_ops(const ListOpsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *LID = (uint32_t *)lds; float *LD = (float *)(LID + BL_MAX);
+    uint32_t *ORD = (uint32_t *)(LD + BL_MAX), *SEL = ORD + BL_MAX, *RI = SEL + BL_MAX, *DI = RI + BL_MAX, *TI = DI + BL_MAX;
+    float *TD = (float *)(TI + BL_MAX);
+    float *DSC = TD + BL_MAX;
+    lds_u8 *QV = (lds_u8 *)(DSC + 64);
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    if (g >= p.n_groups) return;
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC, p.cap};
+    const uint32_t lm = p.lm[g];
+    uint32_t cnt = p.cnt[g];
+    for (uint32_t i = lane; i < cnt; i += 64) { LID[i] = p.ids[(size_t)g * p.lm0 + i]; LD[i] = p.d[(size_t)g * p.lm0 + i]; }
+    F_WSYNC();
+    unsigned long long ndist = 0;
+    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
+        if (lane == 0) { LID[cnt] = p.op_new[op]; LD[cnt] = p.op_d[op]; }
+        F_WSYNC();
+        if (cnt < lm) { cnt++; continue; }                                          // mod.rs:469-471
+        const uint32_t n = cnt + 1;                                                 // mod.rs:474-482: the list + the new element, stable sort by distance
+        for (uint32_t i = lane; i < n; i += 64) {
+            const float di = LD[i]; uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) { const float dj = LD[j]; rank += (dj < di || (dj == di && j < i)) ? 1u : 0u; }
+            ORD[rank] = i;
+        }
+        F_WSYNC();
+        const uint32_t nR = bl_select<OP, LPR>(fp, QV, SEL, RI, DI, n, lm, [&](uint32_t h) { return LID[ORD[h]]; }, [&](uint32_t h) { return LD[ORD[h]]; }, lane, ndist);
+        for (uint32_t i = lane; i < nR; i += 64) { const uint32_t c = ORD[RI[i]]; TI[i] = LID[c]; TD[i] = LD[c]; }
+        F_WSYNC();
+        for (uint32_t i = lane; i < nR; i += 64) { LID[i] = TI[i]; LD[i] = TD[i]; }      // mod.rs:484-485
+        cnt = nR;
+        F_WSYNC();
+    }
+    for (uint32_t i = lane; i < cnt; i += 64) { p.ids[(size_t)g * p.lm0 + i] = LID[i]; p.d[(size_t)g * p.lm0 + i] = LD[i]; }
+    if (lane == 0) { p.cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
+}
+
+template <class OP>
+static hipError_t launch_select_w(hx_engine *e, const SelWParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (2 * BL_MAX + ((p.stride + 15u) & ~15u) + 64) * 4 + nch * 1024;
+    if (e->pitch <= 128) hipLaunchKernelGGL((k_select_w<OP, 8>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
+    else if (e->pitch <= 512) hipLaunchKernelGGL((k_select_w<OP, 32>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
+    else hipLaunchKernelGGL((k_select_w<OP, 64>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
+    return hipGetLastError();
+}
+template <class OP>
+static hipError_t launch_list_ops(hx_engine *e, const ListOpsParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (8 * BL_MAX + 64) * 4 + nch * 1024;
+    if (e->pitch <= 128) hipLaunchKernelGGL((k_list_ops<OP, 8>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+    else if (e->pitch <= 512) hipLaunchKernelGGL((k_list_ops<OP, 32>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+    else hipLaunchKernelGGL((k_list_ops<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+    return hipGetLastError();
+}
+
+static int bl_reserve(hx_engine *e, size_t bytes)
+{
+    HxMirror &mr = e->mirror;
+    if (bytes <= mr.cap_lk) return HX_OK;
+    HX_HIP(e, hipStreamSynchronize(e->stream));
+    if (mr.h_lk) (void)hipHostFree(mr.h_lk);
+    if (mr.d_lk) (void)hipFree(mr.d_lk);
+    mr.h_lk = mr.d_lk = nullptr; mr.cap_lk = 0;
+    const size_t n = bytes + bytes / 2;
+    HX_HIP(e, hipHostMalloc((void **)&mr.h_lk, n, hipHostMallocDefault));
+    HX_HIP(e, hipMalloc((void **)&mr.d_lk, n));
+    mr.cap_lk = n;
+    return HX_OK;
+}
+
+// select_neighbors for n_prob result sets that lie in wsel (d_wl: stride entries per problem, ascending; d_cnt); lm[pr] = list size of the problem's layer.
+// On return out_* point into pinned memory: ids / d with lm0 entries per problem, cnt per problem.
+int hx_engine::biglist_select(uint32_t n_prob, uint32_t stride, const uint32_t *lm, uint32_t lm0,
+                              const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs)
+{
+    if (n_prob == 0) return HX_OK;
+    if (lm0 == 0 || lm0 > 200 || stride == 0 || stride > 1000) return fail(HX_E_ARG, "biglist_select: list size / ef_construction out of range");
+    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_select_w serves dense rows <= 8 KiB");
+    if (!wsel.d_wl || n_prob > wsel.cap_prob || stride > wsel.cap_ef) return fail(HX_E_STATE, "biglist_select: no result sets on the device");
+    HX_HIP(this, hipSetDevice(device));
+    size_t o = 64;
+    const size_t o_lm = o; o += al16((size_t)n_prob * 4);
+    const size_t in_bytes = o;
+    const size_t o_cnt = o; o += al16((size_t)n_prob * 4);
+    const size_t o_ids = o; o += al16((size_t)n_prob * lm0 * 4);
+    const size_t o_d = o; o += al16((size_t)n_prob * lm0 * 4);
+    int rc = bl_reserve(this, o);
+    if (rc) return rc;
+    HxMirror &mr = mirror;
+    memset(mr.h_lk, 0, 64);
+    memcpy(mr.h_lk + o_lm, lm, (size_t)n_prob * 4);
+    HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, in_bytes, hipMemcpyHostToDevice, stream));
+    SelWParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = 0u; p.n_prob = n_prob; p.stride = stride; p.lm0 = lm0;
+    p.wl = (const uint2 *)wsel.d_wl; p.wl_cnt = wsel.d_cnt; p.lm = (const uint32_t *)(mr.d_lk + o_lm);
+    p.out_ids = (uint32_t *)(mr.d_lk + o_ids); p.out_d = (float *)(mr.d_lk + o_d); p.out_cnt = (uint32_t *)(mr.d_lk + o_cnt);
+    p.n_pairs = (unsigned long long *)mr.d_lk;
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_select_w<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_select_w<OpF16<K>>(this, p)
+    HX_DISPATCH(this, F32C, F16C, ls = launch_select_w<OpHamming>(this, p), ls = launch_select_w<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+    HX_HIP(this, ls);
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk, mr.d_lk, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk + o_cnt, mr.d_lk + o_cnt, o - o_cnt, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    unsigned long long np; memcpy(&np, mr.h_lk, 8);
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    *out_cnt = (const uint32_t *)(mr.h_lk + o_cnt); *out_ids = (const uint32_t *)(mr.h_lk + o_ids); *out_d = (const float *)(mr.h_lk + o_d);
+    return HX_OK;
+}
+
+// back-links of one batch, grouped per list: stage (pinned arrays the caller fills: lists with lm0 entries per group, their sizes and counts, the
+// ops of group g at [op_off[g], op_off[g+1])), then biglist_ops_run -> the new lists in the same arrays
+int hx_engine::biglist_ops_stage(uint32_t n_groups, uint32_t n_ops, uint32_t lm0, uint32_t **ids, float **d, uint32_t **cnt, uint32_t **lm, uint32_t **op_off,
+                                 uint32_t **op_new, float **op_d)
+{
+    if (n_groups == 0 || lm0 == 0 || lm0 > 200) return fail(HX_E_ARG, "biglist_ops_stage: bad sizes");
+    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_list_ops serves dense rows <= 8 KiB");
+    HX_HIP(this, hipSetDevice(device));
+    size_t o = 64;
+    bl_o_lm = o; o += al16((size_t)n_groups * 4);
+    bl_o_off = o; o += al16(((size_t)n_groups + 1) * 4);
+    bl_o_new = o; o += al16((size_t)n_ops * 4);
+    bl_o_od = o; o += al16((size_t)n_ops * 4);
+    bl_o_cnt = o; o += al16((size_t)n_groups * 4);
+    bl_o_ids = o; o += al16((size_t)n_groups * lm0 * 4);
+    bl_o_d = o; o += al16((size_t)n_groups * lm0 * 4);
+    bl_end = o;
+    int rc = bl_reserve(this, o);
+    if (rc) return rc;
+    uint8_t *h = mirror.h_lk;
+    memset(h, 0, 64);
+    *ids = (uint32_t *)(h + bl_o_ids); *d = (float *)(h + bl_o_d); *cnt = (uint32_t *)(h + bl_o_cnt); *lm = (uint32_t *)(h + bl_o_lm);
+    *op_off = (uint32_t *)(h + bl_o_off); *op_new = (uint32_t *)(h + bl_o_new); *op_d = (float *)(h + bl_o_od);
+    bl_groups = n_groups; bl_lm0 = lm0;
+    return HX_OK;
+}
+
+int hx_engine::biglist_ops_run(uint64_t *n_pairs)
+{
+    if (bl_groups == 0) return fail(HX_E_STATE, "biglist_ops_run without biglist_ops_stage");
+    HxMirror &mr = mirror;
+    HX_HIP(this, hipSetDevice(device));
+    HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, bl_end, hipMemcpyHostToDevice, stream));
+    ListOpsParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = 0u; p.n_groups = bl_groups; p.lm0 = bl_lm0;
+    p.ids = (uint32_t *)(mr.d_lk + bl_o_ids); p.d = (float *)(mr.d_lk + bl_o_d); p.cnt = (uint32_t *)(mr.d_lk + bl_o_cnt);
+    p.lm = (const uint32_t *)(mr.d_lk + bl_o_lm); p.op_off = (const uint32_t *)(mr.d_lk + bl_o_off); p.op_new = (const uint32_t *)(mr.d_lk + bl_o_new);
+    p.op_d = (const float *)(mr.d_lk + bl_o_od); p.n_pairs = (unsigned long long *)mr.d_lk;
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_list_ops<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_list_ops<OpF16<K>>(this, p)
+    HX_DISPATCH(this, F32C, F16C, ls = launch_list_ops<OpHamming>(this, p), ls = launch_list_ops<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+    HX_HIP(this, ls);
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk, mr.d_lk, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk + bl_o_cnt, mr.d_lk + bl_o_cnt, bl_end - bl_o_cnt, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    unsigned long long np; memcpy(&np, mr.h_lk, 8);
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    bl_groups = 0;
+    return HX_OK;
+}

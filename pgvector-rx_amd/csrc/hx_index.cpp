@@ -1182,6 +1182,34 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
                                nullptr, nullptr, nullptr, tstat.data(), cnts, nullptr, nullptr, 1, &dev))) return ix->fail(rc, e->err);
         ix->prof[6] += hx_index::now_s() - t0;
         ix->counters[1] += cnts[0];
+        static const bool biglist_off = getenv("HX_BIGLIST") && atoi(getenv("HX_BIGLIST")) == 0;     // experiments: select / back-links of these shapes on the lock-step driver
+        if (!biglist_off && e->dtype != HX_SPARSE) {
+            // select_neighbors per (member, layer) in k_select_w (hx_biglist.hip), straight from the result sets the traversal kernel left on the device
+            const uint32_t lm0 = 2u * (uint32_t)g.m;
+            std::vector<uint32_t> lmv(P, lm0);
+            for (uint32_t i = 0; i < n; i++) for (int lc = 0; lc <= std::min(tl[i], bs.entry_level); lc++) lmv[prob[i] + (uint32_t)lc] = (uint32_t)g.lm(lc);
+            const uint32_t *oids = nullptr, *ocnt = nullptr; const float *od = nullptr; uint64_t np = 0;
+            if ((rc = e->biglist_select(P, (uint32_t)ix->efc, lmv.data(), lm0, &oids, &od, &ocnt, &np))) return ix->fail(rc, e->err);
+            ix->counters[2] += np;
+            ix->pool->parallel_for((n + 255) / 256, [&](size_t ci) {
+                for (uint32_t i = (uint32_t)ci * 256; i < std::min<uint32_t>(n, (uint32_t)ci * 256 + 256); i++) {
+                    if (tstat[i] != 0) continue;
+                    const uint32_t id = bs.base + lo + i; const int start = std::min(tl[i], bs.entry_level);
+                    for (int lc = 0; lc <= tl[i]; lc++) {
+                        Cand *lst = g.list(id, lc); uint32_t c = 0;
+                        if (lc <= start) {
+                            const size_t pr = (size_t)prob[i] + (size_t)lc; c = std::min<uint32_t>(ocnt[pr], (uint32_t)g.lm(lc));
+                            for (uint32_t k = 0; k < c; k++) lst[k] = Cand{od[pr * lm0 + k], oids[pr * lm0 + k]};
+                        }
+                        g.cnt(id, lc) = (uint16_t)c;
+                    }
+                    bs.searched[lo + i] = 1;
+                }
+            });
+            for (uint32_t i = 0; i < n; i++) { if (tstat[i] != 0) todo.push_back(lo + i); else ix->mark_dirty(bs.base + lo + i); }
+            ix->fused_tasks += n; ix->fused_redo += todo.size();
+            if (todo.empty()) return HX_OK;
+        } else {
         std::vector<uint32_t> wcnt(P); std::vector<uint2> wl((size_t)P * ix->efc);
         if (hipMemcpyAsync(wcnt.data(), w.d_cnt, (size_t)P * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
             hipMemcpyAsync(wl.data(), w.d_wl, (size_t)P * ix->efc * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
@@ -1221,6 +1249,7 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
         }
         ix->fused_tasks += n; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
+        }
     } else {
         for (uint32_t i = lo; i < hi; i++) todo.push_back(i);
     }
@@ -1445,6 +1474,50 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
                     g.cnt(tg[gi], (int)ly[gi]) = (uint16_t)c;
                 }
             });
+        }
+        bs.linked = true;
+        return HX_OK;
+    }
+    static const bool biglist_off = getenv("HX_BIGLIST") && atoi(getenv("HX_BIGLIST")) == 0;
+    if (ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192 && !biglist_off) {
+        // lists the lane-per-slot kernels do not serve (m > 32: up to 200 slots): k_list_ops (hx_biglist.hip), one wavefront per owned list, from the
+        // list contents the host hands over; the new lists come back into the host copy (the master for these index shapes)
+        auto &own = ix->ls.own; own.clear();
+        for (uint32_t gi = 0; gi < bs.grp.size(); gi++) if (ops[bs.grp[gi].first].target % world == rank) own.push_back(gi);
+        const uint32_t ng = (uint32_t)own.size(), lm0 = 2u * (uint32_t)g.m;
+        if (ng) {
+            auto &off = ix->ls.off; off.assign(ng + 1, 0u);
+            for (uint32_t k = 0; k < ng; k++) off[k + 1] = off[k] + (uint32_t)(bs.grp[own[k]].second - bs.grp[own[k]].first);
+            for (uint32_t k = 0; k < ng; k++) ix->prof[13] = std::max(ix->prof[13], (double)(off[k + 1] - off[k]));
+            ix->prof[14] += off[ng];
+            uint32_t *h_ids, *h_cnt, *h_lm, *h_off, *h_new; float *h_d, *h_od;
+            if ((rc = ix->e->biglist_ops_stage(ng, off[ng], lm0, &h_ids, &h_d, &h_cnt, &h_lm, &h_off, &h_new, &h_od))) return ix->fail(rc, ix->e->err);
+            memcpy(h_off, off.data(), ((size_t)ng + 1) * 4);
+            ix->pool->parallel_for((ng + 1023) / 1024, [&](size_t ci) {
+                for (size_t k = ci * 1024; k < std::min<size_t>(ng, ci * 1024 + 1024); k++) {
+                    const auto &gr = bs.grp[own[k]];
+                    const uint32_t t = ops[gr.first].target; const int ly = ops[gr.first].layer;
+                    const Cand *lst = g.list(t, ly); const uint32_t c = g.cnt(t, ly);
+                    for (uint32_t i = 0; i < c; i++) { h_ids[k * lm0 + i] = lst[i].id; h_d[k * lm0 + i] = lst[i].d; }
+                    h_cnt[k] = c; h_lm[k] = (uint32_t)g.lm(ly);
+                    uint32_t o = off[k];
+                    for (size_t q = gr.first; q < gr.second; q++) { h_new[o] = ops[q].new_id; h_od[o] = ops[q].d; o++; }
+                }
+            });
+            ix->prof[8] += hx_index::now_s() - t_links0;
+            uint64_t np = 0;
+            { hx_index::Timer tl(ix->prof[9]); if ((rc = ix->e->biglist_ops_run(&np))) return ix->fail(rc, ix->e->err); }
+            ix->counters[3] += np;
+            ix->pool->parallel_for((ng + 1023) / 1024, [&](size_t ci) {
+                for (size_t k = ci * 1024; k < std::min<size_t>(ng, ci * 1024 + 1024); k++) {
+                    const auto &gr = bs.grp[own[k]];
+                    const uint32_t t = ops[gr.first].target; const int ly = ops[gr.first].layer;
+                    Cand *lst = g.list(t, ly); const uint32_t c = std::min<uint32_t>(h_cnt[k], (uint32_t)g.lm(ly));
+                    for (uint32_t i = 0; i < c; i++) lst[i] = Cand{h_d[k * lm0 + i], h_ids[k * lm0 + i]};
+                    g.cnt(t, ly) = (uint16_t)c;
+                }
+            });
+            for (uint32_t k = 0; k < ng; k++) ix->dirty.emplace_back(ops[bs.grp[own[k]].first].target, ops[bs.grp[own[k]].first].layer);
         }
         bs.linked = true;
         return HX_OK;
@@ -1869,6 +1942,8 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     if (rc) return rc;
     const int mxl = max_level_for(g.m);
     const bool any_deleted = std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) != g.deleted.end();
+    bool any_unlinkable = any_deleted;                                              // an element get_update_index would give up a slot for (insert.rs:566-625)
+    for (uint32_t i = 0; i < g.size() && !any_unlinkable; i++) if (g.level[i] >= 0 && g.ntids[i] == 0) any_unlinkable = true;
     uint32_t done = 0;
     while (done < n) {
         if (g.entry < 0) {                                                          // first element: insert.rs:1320-1338 (no entry point yet)
@@ -2002,7 +2077,39 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
             // (hx_links.hip) answers the full lists, one wavefront per op, from the list contents the host hands over.
             const bool dev_upd = ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192;
             std::vector<uint32_t> wops, devq; std::vector<int> wres;
-            for (uint32_t wave = 0; dev_upd; wave++) {
+            // no deleted / TID-less element in the index: get_update_index's early exits cannot fire, and k_update_runs applies a list's whole run in one go
+            bool runs_done = false;
+            if (dev_upd && !any_unlinkable) {
+                const uint32_t nr = (uint32_t)runs.size(), stride = 2u * (uint32_t)g.m;
+                uint32_t *h_ids, *h_cnt, *h_lm, *h_off, *h_new; float *h_d, *h_od;
+                if ((rc = ix->e->update_runs_stage(nr, (uint32_t)ops.size(), stride, &h_ids, &h_d, &h_cnt, &h_lm, &h_off, &h_new, &h_od))) return ix->fail(rc, ix->e->err);
+                ix->pool->parallel_for((nr + 1023) / 1024, [&](size_t ci) {
+                    for (size_t k = ci * 1024; k < std::min<size_t>(nr, ci * 1024 + 1024); k++) {
+                        const UOp &o0 = ops[order[runs[k].first]];
+                        const Cand *lst = g.list(o0.nbr, o0.layer); const uint32_t c = g.cnt(o0.nbr, o0.layer);
+                        for (uint32_t i = 0; i < c; i++) { h_ids[k * stride + i] = lst[i].id; h_d[k * stride + i] = lst[i].d; }
+                        h_cnt[k] = c; h_lm[k] = (uint32_t)g.lm(o0.layer); h_off[k] = runs[k].first;
+                        for (uint32_t q = runs[k].first; q < runs[k].second; q++) { h_new[q] = ops[order[q]].id; h_od[q] = ops[order[q]].d; }
+                    }
+                });
+                h_off[nr] = (uint32_t)ops.size();
+                uint64_t np = 0;
+                const double t_k = hx_index::now_s();
+                if ((rc = ix->e->update_runs_run(&np))) return ix->fail(rc, ix->e->err);
+                ix->prof[3] += hx_index::now_s() - t_k; ix->prof[5] += 1.0;
+                ix->counters[3] += np;
+                ix->pool->parallel_for((nr + 1023) / 1024, [&](size_t ci) {
+                    for (size_t k = ci * 1024; k < std::min<size_t>(nr, ci * 1024 + 1024); k++) {
+                        const UOp &o0 = ops[order[runs[k].first]];
+                        Cand *lst = g.list(o0.nbr, o0.layer); const uint32_t c = std::min<uint32_t>(h_cnt[k], (uint32_t)g.lm(o0.layer));
+                        for (uint32_t i = 0; i < c; i++) lst[i] = Cand{h_d[k * stride + i], h_ids[k * stride + i]};
+                        g.cnt(o0.nbr, o0.layer) = (uint16_t)c;
+                    }
+                });
+                for (uint32_t k = 0; k < nr; k++) ix->dirty.emplace_back(ops[order[runs[k].first]].nbr, ops[order[runs[k].first]].layer);
+                runs_done = true;
+            }
+            for (uint32_t wave = 0; dev_upd && !runs_done; wave++) {
                 wops.clear(); devq.clear();
                 for (const auto &r : runs) if (r.first + wave < r.second) wops.push_back(order[r.first + wave]);
                 if (wops.empty()) break;
@@ -2040,7 +2147,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
                     write_neighbor_update(ix, o.nbr, o.layer, o.id, o.d, wres[k]);
                 }
             }
-            for (uint32_t wave = 0; !dev_upd; wave++) {
+            for (uint32_t wave = 0; !dev_upd && !runs_done; wave++) {
                 std::vector<LsTask *> utasks; std::vector<uint32_t> which;
                 for (const auto &r : runs) {
                     if (r.first + wave >= r.second) continue;

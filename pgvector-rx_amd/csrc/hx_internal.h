@@ -168,6 +168,15 @@ struct hx_engine {
     int db_apply(uint32_t base, uint32_t b, const uint32_t *d_rec, const uint8_t *h_dup, uint32_t rank, uint32_t world, uint32_t *n_ops_out);
     int db_import_lists(const uint32_t *d_xrec, uint32_t n_records);
     HxGroupWork grp;
+    // lists of any legal size (hx_biglist.hip): select_neighbors over the result sets in wsel; a batch's back-links per list, stateless
+    int biglist_select(uint32_t n_prob, uint32_t stride, const uint32_t *lm, uint32_t lm0, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs);
+    int biglist_ops_stage(uint32_t n_groups, uint32_t n_ops, uint32_t lm0, uint32_t **ids, float **d, uint32_t **cnt, uint32_t **lm, uint32_t **op_off, uint32_t **op_new, float **op_d);
+    int biglist_ops_run(uint64_t *n_pairs);
+    size_t bl_o_lm = 0, bl_o_off = 0, bl_o_new = 0, bl_o_od = 0, bl_o_cnt = 0, bl_o_ids = 0, bl_o_d = 0, bl_end = 0; uint32_t bl_groups = 0, bl_lm0 = 0;
+    // aminsert: all back-connections of a batch, one wavefront per list (hx_links.hip: k_update_runs): stage -> fill -> run -> the new lists in the same arrays
+    int update_runs_stage(uint32_t n_runs, uint32_t n_ops, uint32_t stride, uint32_t **ids, float **d, uint32_t **cnt, uint32_t **lm, uint32_t **op_off, uint32_t **op_new, float **op_d);
+    int update_runs_run(uint64_t *n_pairs);
+    size_t ur_o_lm = 0, ur_o_off = 0, ur_o_new = 0, ur_o_od = 0, ur_o_cnt = 0, ur_o_ids = 0, ur_o_d = 0, ur_end = 0; uint32_t ur_n = 0, ur_stride = 0;
     // aminsert's get_update_index for one wave of full lists (hx_links.hip: k_update_index): stage -> fill the pinned arrays -> run
     int update_index_stage(uint32_t n_ops, uint32_t stride, uint32_t **ids, float **d, float **new_d, uint32_t **cnt);
     int update_index_run(const int32_t **slot_out, uint64_t *n_pairs);

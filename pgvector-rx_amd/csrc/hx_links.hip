@@ -625,6 +625,144 @@ k_update_index(const UpdParams p)
     if (lane == 0) { p.slot[op] = res; atomicAdd(p.n_pairs, ndist); }
 }
 
+// k_update_runs: every back-connection a batch of aminserts makes to ONE list, applied in order by one wavefront -- write_neighbor_update's "already connected"
+// test (insert.rs:805-812), the free slot (:556-559, :826-838) and k_update_index's walk for a full list, the list kept in LDS between the ops.  For indexes
+// without deleted / TID-less elements (get_update_index's other exits, insert.rs:524-527, 566-625, never fire there); the new list goes back to the host.
+struct UpdRunParams {
+    const uint8_t *rows; uint32_t pitch, n_runs, stride;
+    uint32_t *ids; float *d; uint32_t *cnt;                       // list of run r: ids/d[r * stride ..), cnt[r]  (in and out)
+    const uint32_t *lm, *op_off, *op_new; const float *op_d; unsigned long long *n_pairs;
+};
+
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64, 4)
+k_update_runs(const UpdRunParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *LID = (uint32_t *)lds; float *LD = (float *)(LID + 64);
+    uint32_t *ORD = (uint32_t *)(LD + 64);
+    uint32_t *SEL = ORD + 72, *PRN = SEL + 64;
+    float *DSC = (float *)(PRN + 64);
+    lds_u8 *QV = (lds_u8 *)(DSC + 64);
+    const uint32_t lane = threadIdx.x, r = blockIdx.x;
+    if (r >= p.n_runs) return;
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC};
+    const uint32_t lm = p.lm[r];
+    uint32_t cnt = p.cnt[r];
+    if (lane < cnt) { LID[lane] = p.ids[(size_t)r * p.stride + lane]; LD[lane] = p.d[(size_t)r * p.stride + lane]; }
+    F_WSYNC();
+    unsigned long long ndist = 0;
+    for (uint32_t op = p.op_off[r]; op < p.op_off[r + 1]; op++) {
+        const uint32_t nid = p.op_new[op]; const float nd = p.op_d[op];
+        if (__ballot(lane < cnt && LID[lane] == nid) != 0ull) continue;             // connection already exists
+        if (cnt < lm) { if (lane == 0) { LID[cnt] = nid; LD[cnt] = nd; } cnt++; F_WSYNC(); continue; }
+        const float di = lane < cnt ? LD[lane] : 0.0f;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; j++) { const float dj = LD[j]; rank += (dj < di || (dj == di && j < lane)) ? 1u : 0u; }
+        const uint32_t pn = (uint32_t)__popcll(__ballot(lane < cnt && !(di > nd)));
+        if (lane < cnt) ORD[rank + (di > nd ? 1u : 0u)] = lane;
+        if (lane == 0) ORD[pn] = 64u;
+        F_WSYNC();
+        uint32_t nsel = 0, nselm = 0, npr = 0; bool new_sel = false, kept = false;
+        for (uint32_t h = 0; h <= cnt; h++) {
+            if (nsel >= lm) break;
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ORD[h]);
+            if (s == 64u) { new_sel = true; nsel++; continue; }
+            bool hit = false;
+            if (nselm) {
+                f_park_w(fp, p.rows + (size_t)LID[s] * p.pitch, lane, QV);
+                hit = f_any_le<OP, LPR>(fp, QV, SEL, nselm, lane, LD[s], ndist);
+            }
+            if (!hit) { if (lane == 0) SEL[nselm] = LID[s]; nselm++; nsel++; if (lane == s) kept = true; }
+            else { if (lane == 0) PRN[npr] = s; npr++; }
+            F_WSYNC();
+        }
+        for (uint32_t k = 0; k < npr && nsel < lm; k++, nsel++) if (lane == PRN[k]) kept = true;
+        if (new_sel) {
+            const unsigned long long out = __ballot(lane < cnt && !kept);
+            if (out) { const uint32_t slot = (uint32_t)__builtin_ctzll(out); if (lane == 0) { LID[slot] = nid; LD[slot] = nd; } }
+        }
+        F_WSYNC();
+    }
+    if (lane < cnt) { p.ids[(size_t)r * p.stride + lane] = LID[lane]; p.d[(size_t)r * p.stride + lane] = LD[lane]; }
+    if (lane == 0) { p.cnt[r] = cnt; atomicAdd(p.n_pairs, ndist); }
+}
+
+template <class OP>
+static hipError_t launch_update_runs(hx_engine *e, const UpdRunParams &p)
+{
+    const size_t nch = (e->pitch + 1023) / 1024;
+    const size_t lds = (64 * 5 + 72) * 4 + nch * 1024;
+    if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs<OP, 8>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
+    else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_runs<OP, 32>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
+    else hipLaunchKernelGGL((k_update_runs<OP, 64>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
+    return hipGetLastError();
+}
+
+int hx_engine::update_runs_stage(uint32_t n_runs, uint32_t n_ops, uint32_t stride, uint32_t **ids, float **d, uint32_t **cnt, uint32_t **lm, uint32_t **op_off,
+                                 uint32_t **op_new, float **op_d)
+{
+    HxMirror &mr = mirror;
+    if (n_runs == 0 || stride == 0 || stride > 64) return fail(HX_E_ARG, "update_runs_stage: bad sizes");
+    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_update_runs serves dense rows <= 8 KiB");
+    HX_HIP(this, hipSetDevice(device));
+    size_t o = 64;
+    ur_o_lm = o; o += al16((size_t)n_runs * 4);
+    ur_o_off = o; o += al16(((size_t)n_runs + 1) * 4);
+    ur_o_new = o; o += al16((size_t)n_ops * 4);
+    ur_o_od = o; o += al16((size_t)n_ops * 4);
+    ur_o_cnt = o; o += al16((size_t)n_runs * 4);
+    ur_o_ids = o; o += al16((size_t)n_runs * stride * 4);
+    ur_o_d = o; o += al16((size_t)n_runs * stride * 4);
+    ur_end = o;
+    if (o > mr.cap_lk) {
+        HX_HIP(this, hipStreamSynchronize(stream));
+        if (mr.h_lk) (void)hipHostFree(mr.h_lk);
+        if (mr.d_lk) (void)hipFree(mr.d_lk);
+        mr.h_lk = mr.d_lk = nullptr; mr.cap_lk = 0;
+        const size_t n = o * 2;
+        HX_HIP(this, hipHostMalloc((void **)&mr.h_lk, n, hipHostMallocDefault));
+        HX_HIP(this, hipMalloc((void **)&mr.d_lk, n));
+        mr.cap_lk = n;
+    }
+    uint8_t *h = mr.h_lk;
+    memset(h, 0, 64);
+    *ids = (uint32_t *)(h + ur_o_ids); *d = (float *)(h + ur_o_d); *cnt = (uint32_t *)(h + ur_o_cnt); *lm = (uint32_t *)(h + ur_o_lm);
+    *op_off = (uint32_t *)(h + ur_o_off); *op_new = (uint32_t *)(h + ur_o_new); *op_d = (float *)(h + ur_o_od);
+    ur_n = n_runs; ur_stride = stride;
+    return HX_OK;
+}
+
+int hx_engine::update_runs_run(uint64_t *n_pairs)
+{
+    HxMirror &mr = mirror;
+    if (ur_n == 0) return fail(HX_E_STATE, "update_runs_run without update_runs_stage");
+    HX_HIP(this, hipSetDevice(device));
+    HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, ur_end, hipMemcpyHostToDevice, stream));
+    UpdRunParams p;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.n_runs = ur_n; p.stride = ur_stride;
+    p.ids = (uint32_t *)(mr.d_lk + ur_o_ids); p.d = (float *)(mr.d_lk + ur_o_d); p.cnt = (uint32_t *)(mr.d_lk + ur_o_cnt);
+    p.lm = (const uint32_t *)(mr.d_lk + ur_o_lm); p.op_off = (const uint32_t *)(mr.d_lk + ur_o_off); p.op_new = (const uint32_t *)(mr.d_lk + ur_o_new);
+    p.op_d = (const float *)(mr.d_lk + ur_o_od); p.n_pairs = (unsigned long long *)mr.d_lk;
+    if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
+    hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_update_runs<OpF32<K>>(this, p)
+#define F16C(K) ls = launch_update_runs<OpF16<K>>(this, p)
+    HX_DISPATCH(this, F32C, F16C, ls = launch_update_runs<OpHamming>(this, p), ls = launch_update_runs<OpJaccard>(this, p));
+#undef F32C
+#undef F16C
+    HX_HIP(this, ls);
+    if (timing) HX_HIP(this, hipEventRecord(ev3, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk, mr.d_lk, 64, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipMemcpyAsync(mr.h_lk + ur_o_cnt, mr.d_lk + ur_o_cnt, ur_end - ur_o_cnt, hipMemcpyDeviceToHost, stream));
+    HX_HIP(this, hipStreamSynchronize(stream));
+    unsigned long long np; memcpy(&np, mr.h_lk, 8);
+    if (n_pairs) *n_pairs = np;
+    if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
+    ur_n = 0;
+    return HX_OK;
+}
+
 template <class OP>
 static hipError_t launch_update_index(hx_engine *e, const UpdParams &p)
 {

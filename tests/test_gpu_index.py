@@ -736,8 +736,8 @@ def test_overflowed_tasks_are_retried_on_the_device_with_roomier_tables():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,metric,dim,m", [(hx.F32, hx.L2SQ, 6, 40), (hx.BIT, hx.HAMMING, 64, 100)])
 def test_scans_run_in_the_traversal_kernel_for_every_legal_m(dtype, metric, dim, m):
-    """m in 33..100 (options.rs:203-225): the build falls to the lock-step driver (the insert and back-link kernels serve lists of <= 64), but plain and
-    iterative scans still run inside k_fused, which walks a layer-0 list of up to 200 ids 64 at a time -- same tids as the oracle."""
+    """m in 33..100 (options.rs:203-225): plain and iterative scans run inside k_fused, which walks a layer-0 list of up to 200 ids 64 at a time -- same
+    tids as the oracle."""
     rng = np.random.default_rng(m)
     n, efc = 1200, 2 * m
     rows = make_rows(dtype, n, dim, rng)
@@ -756,6 +756,28 @@ def test_scans_run_in_the_traversal_kernel_for_every_legal_m(dtype, metric, dim,
         assert tids[q, :cnt[q]].tolist() == [t for t, _, _ in o.scan(qs[q], ef_search=60, limit=10)]
         want = [t for t, _, _ in o.scan(qs[q], ef_search=60, iterative=orc.ITER_RELAXED, max_scan_tuples=20000) if passes[t]][:8]
         assert it[0][q, :it[2][q]].tolist() == want
+    ix.close()
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,metric,dim,m,efc,batch", [
+    (hx.F32, hx.L2SQ, 6, 40, 80, 64), (hx.F32, hx.NEG_IP, 24, 64, 128, 200), (hx.F16, hx.L2SQ, 40, 100, 200, 97),
+    (hx.BIT, hx.HAMMING, 64, 100, 200, 64), (hx.F32, hx.L1, 300, 50, 120, 128), (hx.F16, hx.NEG_IP, 600, 33, 70, 1)])
+def test_builds_for_every_legal_m_stay_on_the_device(dtype, metric, dim, m, efc, batch):
+    """m in 33..100 (options.rs:203-225): the searches run in k_fused (MODE 3), select_neighbors in k_select_w and update_neighbor_connections in
+    k_list_ops (hx_biglist.hip: lists of up to 200 slots walked 64 at a time, pair distances evaluated as check_element_closer asks for them).
+    Graph identical to the oracle's (Hamming: ties everywhere), no lock-step round, no task redone."""
+    rng = np.random.default_rng(m + dim)
+    n = 1500
+    rows = make_rows(dtype, n, dim, rng)
+    levels = hx.draw_levels(n, m, seed=m)
+    e, ix, elem, o, oelem = build_both(dtype, metric, dim, rows, levels, m, efc, batch)
+    assert elem.tolist() == oelem.tolist()
+    assert_same_graph(ix, o, n)
+    assert ix.profile()["rounds"] == 0
+    assert ix.fused_stats()["redone"] == 0
+    assert max(len(ix.neighbors(i, 0)[0]) for i in range(n)) == 2 * m          # the lists did fill: back-links were pruned
     ix.close()
     e.close()
 
