@@ -801,6 +801,10 @@ struct hx_index {
     Graph g; int efc = 64;
     std::unique_ptr<Pool> pool; int n_threads = 0;
     uint64_t counters[8] = {0};
+    // true while some live element's list may still name a deleted element (vacuum.rs:300-303 leaves an un-repairable entry point as it is): searches then
+    // meet load_element -> None (scan.rs:178-181) and stay on the lock-step driver.  hx_index_vacuum verifies and clears it; a page image never loads
+    // deleted tuples and hx_index_invalidate unlinks what it drops, so nothing else can set it.
+    bool dead_refs = false;
     std::vector<std::unique_ptr<InsertTask>> insert_pool;      // task objects are reused across batches (their heaps,
     std::vector<std::unique_ptr<BacklinkTask>> backlink_pool;  // visited tables and request vectors keep their capacity)
     std::vector<std::unique_ptr<QueryTask>> query_pool;
@@ -1942,8 +1946,9 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     if (rc) return rc;
     const int mxl = max_level_for(g.m);
     const bool any_deleted = std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) != g.deleted.end();
-    bool any_unlinkable = any_deleted;                                              // an element get_update_index would give up a slot for (insert.rs:566-625)
-    for (uint32_t i = 0; i < g.size() && !any_unlinkable; i++) if (g.level[i] >= 0 && g.ntids[i] == 0) any_unlinkable = true;
+    const bool dead_reachable = any_deleted && (ix->dead_refs || (g.entry >= 0 && g.deleted[g.entry]));   // deleted elements nobody links to are never met
+    bool any_unlinkable = dead_reachable;                                           // an element get_update_index would give up a slot for (insert.rs:566-625)
+    for (uint32_t i = 0; i < g.size() && !any_unlinkable; i++) if (g.level[i] >= 0 && g.ntids[i] == 0 && !g.deleted[i]) any_unlinkable = true;
     uint32_t done = 0;
     while (done < n) {
         if (g.entry < 0) {                                                          // first element: insert.rs:1320-1338 (no entry point yet)
@@ -1960,13 +1965,13 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
         // batch > 1: what concurrent backends do -- each searches without seeing the others' uncommitted elements, e.g. 013's 10 pgbench clients).
         // Device-resident placement: find_element_neighbors_on_disk (insert.rs:1021-1123) is the traversal kernel's MODE 3 -- the greedy descent and a
         // search_layer per layer, the sorted result set W of every layer handed out -- and its "filtered.iter().rev().take(lm)" (:1111-1117) the first lm
-        // entries of W.  (An index that holds deleted elements -- between VACUUM's passes they are skipped by load_element, scan.rs:178-181 -- and what the
-        // kernel does not serve go through the lock-step driver, as does every member whose tables overflow.)
+        // entries of W.  (An index in which a deleted element can still be reached -- load_element skips those, scan.rs:178-181; hx_index::dead_refs -- and what
+        // the kernel does not serve go through the lock-step driver, as does every member whose tables overflow.)
         std::vector<std::vector<std::vector<Cand>>> nbs(b);                          // [member][layer]: nearest first
         std::vector<int> mlv(b);
         for (uint32_t i = 0; i < b; i++) { int lv = std::min(levels[done + i], mxl); if (lv < 0) lv = 0; mlv[i] = lv; nbs[i].assign(lv + 1, {}); }
         std::vector<uint32_t> ls_members;                                            // members for the lock-step driver
-        if (ix->fused_scan_ok() && !any_deleted && b >= 1) {
+        if (ix->fused_scan_ok() && !dead_reachable && b >= 1) {
             if ((rc = ix->sync_mirror())) return rc;
             hx_engine *e = ix->e;
             std::vector<uint32_t> qsel(b), prob(b), tstat(b); std::vector<int32_t> tl(b);
@@ -2208,9 +2213,11 @@ int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uin
     // repairs `elems` (each against `entries[i]`) in lock-step, then overwrites their neighbour tuples (vacuum.rs:288-407)
     // Device placement of the repair searches (round 3): k_fused MODE 3 with search_layer_disk's semantics, the skip set (the dead elements + the repaired
     // element itself: traversed, not counted, not selected; ef_construction + 1) and a per-task entry point; the lm nearest of every layer's W that are
-    // not in the skip set become the element's new lists.  Used while the index holds no element deleted by an EARLIER vacuum (load_element would skip
-    // those; they are unlinked, but the lock-step driver keeps the letter of scan.rs:178-181), for rows the kernel serves and m <= 32.
-    const bool dev_repair = ix->fused_scan_ok() && 2 * g.m <= 64 && std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) == g.deleted.end();
+    // not in the skip set become the element's new lists.  Used while no element deleted by an EARLIER vacuum can be reached (load_element would skip
+    // those, scan.rs:178-181: the closing check of the vacuum that deleted them found no list naming one -- hx_index::dead_refs), for rows the kernel
+    // serves and m <= 32.
+    const bool dev_repair = ix->fused_scan_ok() && 2 * g.m <= 64 && (!ix->dead_refs || std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) == g.deleted.end());
+    ix->dead_refs = true;                                                           // until the closing check below says otherwise
     uint8_t *d_skip = nullptr;
     struct SkipFree { uint8_t *&p; ~SkipFree() { if (p) (void)hipFree(p); } } skip_free{d_skip};
     if (dev_repair && n) {
@@ -2333,6 +2340,16 @@ int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uin
     }
     if (n_deleted_out) *n_deleted_out = n_del;
     if (n_repaired_out) *n_repaired_out = n_rep;
+    {   // closing check: does any live element still name a deleted one?  (only an entry point vacuum.rs:300-303 could not repair)
+        std::atomic<bool> refs{false};
+        ix->pool->parallel_for((n + 4095) / 4096, [&](size_t ci) {
+            for (uint32_t e = (uint32_t)ci * 4096; e < std::min<uint32_t>(n, (uint32_t)ci * 4096 + 4096); e++) {
+                if (g.level[e] < 0 || g.deleted[e]) continue;
+                for (int lc = 0; lc <= g.level[e]; lc++) { const Cand *l = g.list(e, lc); for (uint16_t k = 0; k < g.cnt(e, lc); k++) if (g.deleted[l[k].id]) refs.store(true, std::memory_order_relaxed); }
+            }
+        });
+        ix->dead_refs = refs.load();
+    }
     return HX_OK;
 }
 

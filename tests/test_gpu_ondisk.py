@@ -277,6 +277,79 @@ def test_sparsevec_vacuum_insert_rounds_on_device():
     e.close()
 
 
+@pytest.mark.parametrize("dtype,metric,dim", [(hx.F32, hx.L2SQ, 12), (hx.BIT, hx.HAMMING, 64)])
+def test_insert_vacuum_rounds_stay_on_the_device(dtype, metric, dim):
+    """Rounds of aminserts and VACUUMs (the shape of tests/t/038): once a vacuum has unlinked what it deleted (its closing check finds no list naming a
+    deleted element) the next inserts and the next vacuum's repair searches run in the traversal kernel again -- load_element's skip of deleted tuples
+    (scan.rs:178-181) can no longer be met -- and the graph after every round is the oracle's."""
+    rng = np.random.default_rng(dim)
+    per, rounds, m, efc = 250, 3, 8, 32
+    n = per * rounds
+    rows = make_rows(dtype, n, dim, rng)
+    levels = hx.draw_levels(n, m, seed=5)
+    e = hx.Engine(dtype, metric, dim, n)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    o = orc.Index(dtype, metric, dim, m=m, ef_construction=efc, order=orc.W64)
+    o.set_ondisk_tombstones(True)
+    dead = set()
+    for r in range(rounds):
+        tids = np.arange(r * per + 1, r * per + per + 1, dtype=np.int64)
+        before = ix.fused_stats()
+        rounds_before = ix.profile()["rounds"]
+        ix.insert_ondisk(r * per, levels[r * per:(r + 1) * per], tids=tids, batch=1)
+        after = ix.fused_stats()
+        assert after["tasks"] - before["tasks"] >= per - 1 and after["redone"] == before["redone"]      # every neighbour search was a device task
+        assert ix.profile()["rounds"] - rounds_before <= 2 * per                                       # get_update_index: one kernel per insert, no expansion rounds
+        for i in range(per):
+            o.insert_on_disk(rows[r * per + i], int(levels[r * per + i]), int(tids[i]))
+        kill = np.asarray([t for t in range(1, (r + 1) * per + 1) if t % 3 == 0 and t not in dead], np.int64)
+        before = ix.fused_stats()["tasks"]
+        ix.vacuum(kill, batch=1)                                                                       # one repair at a time: the reference's (and the oracle's) order
+        assert ix.fused_stats()["tasks"] > before                                                      # repair searches on the device, also after an earlier vacuum
+        o.vacuum(kill)
+        dead.update(kill.tolist())
+        size = (r + 1) * per
+        assert [ix.deleted(i) for i in range(size)] == [o.deleted(i) for i in range(size)]
+        assert_same_graph(ix, o, size)
+    ix.close()
+    e.close()
+
+
+def test_unrepairable_entry_point_keeps_the_lock_step_driver():
+    """vacuum.rs:300-303 does not repair an element against itself: when everything but the entry point dies its lists keep naming deleted elements, the
+    vacuum's closing check sees that, and the following inserts (which meet load_element -> None, scan.rs:178-181) run on the lock-step driver -- same
+    graph as the oracle's."""
+    rng = np.random.default_rng(303)
+    n0, extra, dim, m, efc = 60, 40, 6, 4, 16
+    rows = make_rows(hx.F32, n0 + extra, dim, rng)
+    levels = hx.draw_levels(n0 + extra, m, seed=9)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n0 + extra)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    o = orc.Index(hx.F32, hx.L2SQ, dim, m=m, ef_construction=efc, order=orc.W64)
+    o.set_ondisk_tombstones(True)
+    tids = np.arange(1, n0 + extra + 1, dtype=np.int64)
+    ix.insert_ondisk(0, levels[:n0], tids=tids[:n0], batch=1)
+    for i in range(n0):
+        o.insert_on_disk(rows[i], int(levels[i]), int(tids[i]))
+    keep = ix.entry
+    kill = np.asarray([t for t in tids[:n0] if t != keep + 1], np.int64)
+    ix.vacuum(kill, batch=1)
+    o.vacuum(kill)
+    assert [ix.deleted(i) for i in range(n0)] == [o.deleted(i) for i in range(n0)] and sum(ix.deleted(i) for i in range(n0)) == n0 - 1
+    assert_same_graph(ix, o, n0)
+    assert any(ix.deleted(int(j)) for j in ix.neighbors(keep, 0)[0])          # the survivor still names deleted elements
+    before = ix.fused_stats()["tasks"]
+    ix.insert_ondisk(n0, levels[n0:], tids=tids[n0:], batch=1)
+    assert ix.fused_stats()["tasks"] == before                                 # no device search while deleted elements can be met
+    for i in range(n0, n0 + extra):
+        o.insert_on_disk(rows[i], int(levels[i]), int(tids[i]))
+    assert_same_graph(ix, o, n0 + extra)
+    ix.close()
+    e.close()
+
+
 @pytest.mark.parametrize("dtype,metric,dim", [(hx.F32, hx.L2SQ, 48), (hx.BIT, hx.HAMMING, 64), (hx.F16, hx.NEG_IP, 300)])
 def test_ondisk_batches_device_search_equals_lock_step_search(dtype, metric, dim):
     """Concurrent aminserts (batch > 1, several calls in a row): the placement that searches in the traversal kernel (MODE 3, search_layer_disk semantics)
