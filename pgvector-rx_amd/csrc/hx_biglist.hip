@@ -7,6 +7,7 @@
 // copy for these index shapes); distances are the canonical ones, so lists and distance bits equal the lock-step driver's and the oracle's.
 //   k_select_w   one wavefront per (new element, layer): select_neighbors over the result set W the traversal kernel (MODE 3) left on the device
 //   k_list_ops   one wavefront per (neighbour, layer) list: its back-links of the batch applied in insertion order
+//   k_update_runs_big   the same for aminsert's back-connections (get_update_index + write_neighbor_update, insert.rs:500-871)
 #include "hx_fused_core.h"
 
 #define BL_MAX 208            /* lm <= 200, + the new element, rounded up */
@@ -114,6 +115,70 @@ k_list_ops(const ListOpsParams p)
     if (lane == 0) { p.cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
 }
 
+// k_update_runs (hx_links.hip) for lists of more than 64 slots: every back-connection a batch of aminserts makes to one list, applied in order --
+// "already connected" (insert.rs:805-812), the free slot (:556-559), else get_update_index's walk (insert.rs:630-737): the members stable-sorted by
+// distance with the new element behind every member that is not farther, a member kept when no kept MEMBER lies at least as close to it as the
+// owner does (pairs with the new element are skipped), pruned members filling up in order, the new element replacing the first member not kept.
+template <class OP, int LPR>
+__global__ void __launch_bounds__(64, 4)
+k_update_runs_big(const ListOpsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t *LID = (uint32_t *)lds; float *LD = (float *)(LID + BL_MAX);
+    uint32_t *ORD = (uint32_t *)(LD + BL_MAX), *SEL = ORD + BL_MAX, *KEPT = SEL + BL_MAX, *PRN = KEPT + BL_MAX;
+    float *DSC = (float *)(PRN + 3 * BL_MAX);                                       // same carve as k_list_ops (8 arrays)
+    lds_u8 *QV = (lds_u8 *)(DSC + 64);
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    if (g >= p.n_groups) return;
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC, p.cap};
+    const uint32_t lm = p.lm[g];
+    uint32_t cnt = p.cnt[g];
+    for (uint32_t i = lane; i < cnt; i += 64) { LID[i] = p.ids[(size_t)g * p.lm0 + i]; LD[i] = p.d[(size_t)g * p.lm0 + i]; }
+    F_WSYNC();
+    unsigned long long ndist = 0;
+    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
+        const uint32_t nid = p.op_new[op]; const float nd = p.op_d[op];
+        bool ex = false;
+        for (uint32_t i = lane; i < cnt; i += 64) ex = ex || LID[i] == nid;
+        if (__ballot(ex) != 0ull) continue;                                         // connection already exists
+        if (cnt < lm) { if (lane == 0) { LID[cnt] = nid; LD[cnt] = nd; } cnt++; F_WSYNC(); continue; }
+        uint32_t pn = 0;                                                            // the new element sorts behind every member with d <= new_d
+        for (uint32_t c0 = 0; c0 < cnt; c0 += 64) pn += (uint32_t)__popcll(__ballot(c0 + lane < cnt && !(LD[c0 + lane < cnt ? c0 + lane : 0] > nd)));
+        for (uint32_t i = lane; i < cnt; i += 64) {
+            const float di = LD[i]; uint32_t rank = 0;
+            for (uint32_t j = 0; j < cnt; j++) { const float dj = LD[j]; rank += (dj < di || (dj == di && j < i)) ? 1u : 0u; }
+            ORD[rank + (di > nd ? 1u : 0u)] = i; KEPT[i] = 0u;
+        }
+        if (lane == 0) ORD[pn] = 0xFFFFFFFFu;
+        F_WSYNC();
+        uint32_t nsel = 0, nselm = 0, npr = 0; bool new_sel = false;
+        for (uint32_t h = 0; h <= cnt; h++) {
+            if (nsel >= lm) break;
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ORD[h]);
+            if (s == 0xFFFFFFFFu) { new_sel = true; nsel++; continue; }
+            bool hit = false;
+            if (nselm) {
+                f_park_w(fp, p.rows + (size_t)LID[s] * p.pitch, lane, QV);
+                hit = f_any_le<OP, LPR>(fp, QV, SEL, nselm, lane, LD[s], ndist);
+            }
+            if (!hit) { if (lane == 0) { SEL[nselm] = LID[s]; KEPT[s] = 1u; } nselm++; nsel++; }
+            else { if (lane == 0) PRN[npr] = s; npr++; }
+            F_WSYNC();
+        }
+        for (uint32_t k = 0; k < npr && nsel < lm; k++, nsel++) if (lane == 0) KEPT[PRN[k]] = 1u;   // insert.rs:707-712
+        F_WSYNC();
+        if (new_sel) {
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+                const unsigned long long out = __ballot(c0 + lane < cnt && KEPT[c0 + lane < cnt ? c0 + lane : 0] == 0u);
+                if (out) { if (lane == 0) { const uint32_t slot = c0 + (uint32_t)__builtin_ctzll(out); LID[slot] = nid; LD[slot] = nd; } break; }   // insert.rs:722-737
+            }
+        }
+        F_WSYNC();
+    }
+    for (uint32_t i = lane; i < cnt; i += 64) { p.ids[(size_t)g * p.lm0 + i] = LID[i]; p.d[(size_t)g * p.lm0 + i] = LD[i]; }
+    if (lane == 0) { p.cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
+}
+
 template <class OP>
 static hipError_t launch_select_w(hx_engine *e, const SelWParams &p)
 {
@@ -125,10 +190,16 @@ static hipError_t launch_select_w(hx_engine *e, const SelWParams &p)
     return hipGetLastError();
 }
 template <class OP>
-static hipError_t launch_list_ops(hx_engine *e, const ListOpsParams &p)
+static hipError_t launch_list_ops(hx_engine *e, const ListOpsParams &p, bool disk)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
     const size_t lds = (8 * BL_MAX + 64) * 4 + nch * 1024;
+    if (disk) {
+        if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs_big<OP, 8>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+        else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_runs_big<OP, 32>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+        else hipLaunchKernelGGL((k_update_runs_big<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+        return hipGetLastError();
+    }
     if (e->pitch <= 128) hipLaunchKernelGGL((k_list_ops<OP, 8>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
     else if (e->pitch <= 512) hipLaunchKernelGGL((k_list_ops<OP, 32>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
     else hipLaunchKernelGGL((k_list_ops<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
@@ -223,7 +294,7 @@ int hx_engine::biglist_ops_stage(uint32_t n_groups, uint32_t n_ops, uint32_t lm0
     return HX_OK;
 }
 
-int hx_engine::biglist_ops_run(uint64_t *n_pairs)
+int hx_engine::biglist_ops_run(uint64_t *n_pairs, bool disk)
 {
     if (bl_groups == 0) return fail(HX_E_STATE, "biglist_ops_run without biglist_ops_stage");
     HxMirror &mr = mirror;
@@ -236,9 +307,9 @@ int hx_engine::biglist_ops_run(uint64_t *n_pairs)
     p.op_d = (const float *)(mr.d_lk + bl_o_od); p.n_pairs = (unsigned long long *)mr.d_lk;
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
-#define F32C(K) ls = launch_list_ops<OpF32<K>>(this, p)
-#define F16C(K) ls = launch_list_ops<OpF16<K>>(this, p)
-    HX_DISPATCH(this, F32C, F16C, ls = launch_list_ops<OpHamming>(this, p), ls = launch_list_ops<OpJaccard>(this, p));
+#define F32C(K) ls = launch_list_ops<OpF32<K>>(this, p, disk)
+#define F16C(K) ls = launch_list_ops<OpF16<K>>(this, p, disk)
+    HX_DISPATCH(this, F32C, F16C, ls = launch_list_ops<OpHamming>(this, p, disk), ls = launch_list_ops<OpJaccard>(this, p, disk));
 #undef F32C
 #undef F16C
     HX_HIP(this, ls);

@@ -1939,7 +1939,9 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     if (ix->bs.open) return ix->fail(HX_E_STATE, "a staged batch is open");
     if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
     if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
-    if (2 * g.m > (int)HX_PAIR_MAX_ROWS) return ix->fail(HX_E_ARG, "the on-disk insert path serves m <= 32");
+    const bool big = 2 * g.m > (int)HX_PAIR_MAX_ROWS;                               // lists of more than 64 slots: device kernels only (hx_biglist.hip)
+    if (big && !(ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192))
+        return ix->fail(HX_E_ARG, "m > 32: the on-disk insert path runs in the device kernels only (dense rows <= 8 KiB, hx_index_set_fused(1))");
     if (batch == 0) batch = 1;
     hx_index::Timer t_all(ix->prof[10]);
     int rc = ix->ensure_host_lists();
@@ -1949,6 +1951,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     const bool dead_reachable = any_deleted && (ix->dead_refs || (g.entry >= 0 && g.deleted[g.entry]));   // deleted elements nobody links to are never met
     bool any_unlinkable = dead_reachable;                                           // an element get_update_index would give up a slot for (insert.rs:566-625)
     for (uint32_t i = 0; i < g.size() && !any_unlinkable; i++) if (g.level[i] >= 0 && g.ntids[i] == 0 && !g.deleted[i]) any_unlinkable = true;
+    if (big && any_unlinkable) return ix->fail(HX_E_STATE, "m > 32: the on-disk insert path needs an index whose deleted elements are unlinked (VACUUM to completion first)");
     uint32_t done = 0;
     while (done < n) {
         if (g.entry < 0) {                                                          // first element: insert.rs:1320-1338 (no entry point yet)
@@ -2087,7 +2090,8 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
             if (dev_upd && !any_unlinkable) {
                 const uint32_t nr = (uint32_t)runs.size(), stride = 2u * (uint32_t)g.m;
                 uint32_t *h_ids, *h_cnt, *h_lm, *h_off, *h_new; float *h_d, *h_od;
-                if ((rc = ix->e->update_runs_stage(nr, (uint32_t)ops.size(), stride, &h_ids, &h_d, &h_cnt, &h_lm, &h_off, &h_new, &h_od))) return ix->fail(rc, ix->e->err);
+                if ((rc = big ? ix->e->biglist_ops_stage(nr, (uint32_t)ops.size(), stride, &h_ids, &h_d, &h_cnt, &h_lm, &h_off, &h_new, &h_od)
+                              : ix->e->update_runs_stage(nr, (uint32_t)ops.size(), stride, &h_ids, &h_d, &h_cnt, &h_lm, &h_off, &h_new, &h_od))) return ix->fail(rc, ix->e->err);
                 ix->pool->parallel_for((nr + 1023) / 1024, [&](size_t ci) {
                     for (size_t k = ci * 1024; k < std::min<size_t>(nr, ci * 1024 + 1024); k++) {
                         const UOp &o0 = ops[order[runs[k].first]];
@@ -2100,7 +2104,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
                 h_off[nr] = (uint32_t)ops.size();
                 uint64_t np = 0;
                 const double t_k = hx_index::now_s();
-                if ((rc = ix->e->update_runs_run(&np))) return ix->fail(rc, ix->e->err);
+                if ((rc = big ? ix->e->biglist_ops_run(&np, true) : ix->e->update_runs_run(&np))) return ix->fail(rc, ix->e->err);
                 ix->prof[3] += hx_index::now_s() - t_k; ix->prof[5] += 1.0;
                 ix->counters[3] += np;
                 ix->pool->parallel_for((nr + 1023) / 1024, [&](size_t ci) {
@@ -2215,8 +2219,8 @@ int hx_index_vacuum(hx_index *ix, const int64_t *dead_tids, uint64_t n_dead, uin
     // element itself: traversed, not counted, not selected; ef_construction + 1) and a per-task entry point; the lm nearest of every layer's W that are
     // not in the skip set become the element's new lists.  Used while no element deleted by an EARLIER vacuum can be reached (load_element would skip
     // those, scan.rs:178-181: the closing check of the vacuum that deleted them found no list naming one -- hx_index::dead_refs), for rows the kernel
-    // serves and m <= 32.
-    const bool dev_repair = ix->fused_scan_ok() && 2 * g.m <= 64 && (!ix->dead_refs || std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) == g.deleted.end());
+    // serves.
+    const bool dev_repair = ix->fused_scan_ok() && (!ix->dead_refs || std::find(g.deleted.begin(), g.deleted.end(), (uint8_t)1) == g.deleted.end());
     ix->dead_refs = true;                                                           // until the closing check below says otherwise
     uint8_t *d_skip = nullptr;
     struct SkipFree { uint8_t *&p; ~SkipFree() { if (p) (void)hipFree(p); } } skip_free{d_skip};

@@ -171,7 +171,7 @@ struct hx_engine {
     // lists of any legal size (hx_biglist.hip): select_neighbors over the result sets in wsel; a batch's back-links per list, stateless
     int biglist_select(uint32_t n_prob, uint32_t stride, const uint32_t *lm, uint32_t lm0, const uint32_t **out_ids, const float **out_d, const uint32_t **out_cnt, uint64_t *n_pairs);
     int biglist_ops_stage(uint32_t n_groups, uint32_t n_ops, uint32_t lm0, uint32_t **ids, float **d, uint32_t **cnt, uint32_t **lm, uint32_t **op_off, uint32_t **op_new, float **op_d);
-    int biglist_ops_run(uint64_t *n_pairs);
+    int biglist_ops_run(uint64_t *n_pairs, bool disk = false);   // disk: aminsert's get_update_index / write_neighbor_update instead of update_neighbor_connections
     size_t bl_o_lm = 0, bl_o_off = 0, bl_o_new = 0, bl_o_od = 0, bl_o_cnt = 0, bl_o_ids = 0, bl_o_d = 0, bl_end = 0; uint32_t bl_groups = 0, bl_lm0 = 0;
     // aminsert: all back-connections of a batch, one wavefront per list (hx_links.hip: k_update_runs): stage -> fill -> run -> the new lists in the same arrays
     int update_runs_stage(uint32_t n_runs, uint32_t n_ops, uint32_t stride, uint32_t **ids, float **d, uint32_t **cnt, uint32_t **lm, uint32_t **op_off, uint32_t **op_new, float **op_d);

@@ -22,6 +22,8 @@ CASES = [
     (hx.F16, hx.L1, 12, 500, 16, 64),
     (hx.BIT, hx.HAMMING, 64, 700, 6, 24),       # ties everywhere: stable sorts and heap order decide
     (hx.F32, hx.L2SQ, 3, 500, 20, 48),          # m = 20: lists of 40 (the pair blocks of get_update_index reach 40 rows)
+    (hx.F32, hx.L2SQ, 5, 500, 40, 90),          # m > 32: lists of 80 slots -- k_update_runs_big (hx_biglist.hip)
+    (hx.BIT, hx.HAMMING, 64, 450, 100, 200),    # the largest legal m (options.rs:203-225), ties everywhere
 ]
 
 
@@ -77,7 +79,7 @@ def test_ondisk_insert_into_a_built_index():
     e.close()
 
 
-@pytest.mark.parametrize("dtype,metric,dim,m,efc", [(hx.F32, hx.L2SQ, 3, 4, 8), (hx.BIT, hx.HAMMING, 40, 8, 32)])
+@pytest.mark.parametrize("dtype,metric,dim,m,efc", [(hx.F32, hx.L2SQ, 3, 4, 8), (hx.BIT, hx.HAMMING, 40, 8, 32), (hx.F32, hx.L2SQ, 4, 40, 80)])
 def test_vacuum_identical_to_oracle(dtype, metric, dim, m, efc):
     rng = np.random.default_rng(14 + dim)
     n = 1500
