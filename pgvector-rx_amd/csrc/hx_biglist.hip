@@ -1,9 +1,9 @@
 // hx_biglist.hip -- select_neighbors (graph/mod.rs:269-339) and update_neighbor_connections (mod.rs:442-489) for lists of ANY legal size
 // (options.rs:203-225: m <= 100, so layer-0 lists of up to 200 and result sets W of up to ef_construction <= 1000 candidates).  The kernels of
 // hx_links.hip keep a list in one wavefront's lanes and its pair matrix in LDS (m <= 32); here a list lives in LDS arrays walked 64 entries at a
-// time and no pair matrix is formed at all: a candidate's row is parked in LDS and the rows selected so far are streamed past it with the
-// reference's early exit (f_any_le: FUSED_RB rows per memory round trip), i.e. exactly the distance evaluations check_element_closer makes, in
-// its order, a few rows further at most.  Stateless: the host hands the lists over as they stand and takes the new ones back (it is the master
+// time and the pair matrix is never formed as a whole: a candidate's row is parked in LDS and the rows selected so far are streamed past it with the
+// reference's early exit (FUSED_RB rows per memory round trip), i.e. the distance evaluations check_element_closer makes, in its order, a few
+// rows further at most; k_list_ops remembers them per list across the back-links of a batch (pair memo, below).  Stateless: the host hands the lists over as they stand and takes the new ones back (it is the master
 // copy for these index shapes); distances are the canonical ones, so lists and distance bits equal the lock-step driver's and the oracle's.
 //   k_select_w   one wavefront per (new element, layer): select_neighbors over the result set W the traversal kernel (MODE 3) left on the device
 //   k_list_ops   one wavefront per (neighbour, layer) list: its back-links of the batch applied in insertion order
@@ -75,39 +75,95 @@ struct ListOpsParams {
     const uint32_t *lm, *op_off, *op_new; const float *op_d; unsigned long long *n_pairs;
 };
 
+// Pair memo of k_list_ops: the candidates of one list carry HANDLES (0..lm; a list position keeps its handle while the element stays, the element a
+// back-link drops hands its handle to the next newcomer) and M[tri(ha, hb)] (LDS, packed lower triangle over lm + 1 handles) holds every pair distance
+// evaluated so far for the list, NaN = not yet.  Consecutive back-links to one list re-walk nearly the same candidates, so after the first op of a run
+// almost every check_element_closer is answered from M and only the newcomer's pairs are evaluated -- the job the resident pair matrix does for
+// lists of <= 32 slots (hx_links.hip), without ever forming the whole matrix.
+__device__ __forceinline__ uint32_t bl_tri(uint32_t a, uint32_t b) { const uint32_t hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi - 1u) / 2u + lo; }
+
 template <class OP, int LPR>
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, 1)
 k_list_ops(const ListOpsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *LID = (uint32_t *)lds; float *LD = (float *)(LID + BL_MAX);
-    uint32_t *ORD = (uint32_t *)(LD + BL_MAX), *SEL = ORD + BL_MAX, *RI = SEL + BL_MAX, *DI = RI + BL_MAX, *TI = DI + BL_MAX;
-    float *TD = (float *)(TI + BL_MAX);
-    float *DSC = TD + BL_MAX;
+    uint32_t *HND = (uint32_t *)(LD + BL_MAX), *ORD = HND + BL_MAX, *SEL = ORD + BL_MAX, *SELH = SEL + BL_MAX, *RI = SELH + BL_MAX, *DI = RI + BL_MAX;
+    uint32_t *TI = DI + BL_MAX; float *TD = (float *)(TI + BL_MAX); uint32_t *TH = (uint32_t *)(TD + BL_MAX), *USED = TH + BL_MAX, *MID = USED + BL_MAX, *MH = MID + BL_MAX;
+    float *DSC = (float *)(MH + BL_MAX);
     lds_u8 *QV = (lds_u8 *)(DSC + 64);
+    const uint32_t nch = (p.pitch + 1023u) / 1024u;
+    float *M = (float *)((uint8_t *)QV + nch * 1024u);                              // (lm0 + 1) lm0 / 2 entries
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     if (g >= p.n_groups) return;
-    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC, p.cap};
+    const FRows fp{p.rows, p.pitch, nch, DSC, p.cap};
     const uint32_t lm = p.lm[g];
     uint32_t cnt = p.cnt[g];
-    for (uint32_t i = lane; i < cnt; i += 64) { LID[i] = p.ids[(size_t)g * p.lm0 + i]; LD[i] = p.d[(size_t)g * p.lm0 + i]; }
+    for (uint32_t i = lane; i < cnt; i += 64) { LID[i] = p.ids[(size_t)g * p.lm0 + i]; LD[i] = p.d[(size_t)g * p.lm0 + i]; HND[i] = i; }
+    const float qnan = __builtin_nanf("");
+    for (uint32_t i = lane; i < (lm + 1u) * lm / 2u; i += 64) M[i] = qnan;
+    uint32_t hfree = lm;                                                            // the handle no list position holds once the list is full
     F_WSYNC();
     unsigned long long ndist = 0;
+    constexpr uint32_t B = f_step_rows<LPR>();
     for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
-        if (lane == 0) { LID[cnt] = p.op_new[op]; LD[cnt] = p.op_d[op]; }
-        F_WSYNC();
-        if (cnt < lm) { cnt++; continue; }                                          // mod.rs:469-471
+        if (cnt < lm) {                                                             // mod.rs:469-471
+            if (lane == 0) { LID[cnt] = p.op_new[op]; LD[cnt] = p.op_d[op]; HND[cnt] = cnt; }
+            cnt++; F_WSYNC();
+            continue;
+        }
         const uint32_t n = cnt + 1;                                                 // mod.rs:474-482: the list + the new element, stable sort by distance
+        if (lane == 0) { LID[cnt] = p.op_new[op]; LD[cnt] = p.op_d[op]; HND[cnt] = hfree; }
+        for (uint32_t j = lane; j <= lm; j += 64) if (j != hfree) M[bl_tri(hfree, j)] = qnan;   // the handle's previous owner is gone
+        F_WSYNC();
         for (uint32_t i = lane; i < n; i += 64) {
             const float di = LD[i]; uint32_t rank = 0;
             for (uint32_t j = 0; j < n; j++) { const float dj = LD[j]; rank += (dj < di || (dj == di && j < i)) ? 1u : 0u; }
-            ORD[rank] = i;
+            ORD[rank] = i; USED[i] = 0u;
         }
         F_WSYNC();
-        const uint32_t nR = bl_select<OP, LPR>(fp, QV, SEL, RI, DI, n, lm, [&](uint32_t h) { return LID[ORD[h]]; }, [&](uint32_t h) { return LD[ORD[h]]; }, lane, ndist);
-        for (uint32_t i = lane; i < nR; i += 64) { const uint32_t c = ORD[RI[i]]; TI[i] = LID[c]; TD[i] = LD[c]; }
+        uint32_t nR = 0, nD = 0;
+        for (uint32_t h = 0; h < n; h++) {                                          // select_neighbors, mod.rs:269-308 (n > lm always)
+            if (nR >= lm) break;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)ORD[h]);
+            const uint32_t hc = (uint32_t)__builtin_amdgcn_readfirstlane((int)HND[c]);
+            const float dc = LD[c];
+            bool hit = false; uint32_t nmiss = 0;
+            for (uint32_t k0 = 0; k0 < nR && !hit; k0 += 64) {                      // what the memo already knows
+                const uint32_t k = k0 + lane; const bool in = k < nR;
+                const float v = in ? M[bl_tri(hc, SELH[k])] : 0.0f;
+                const bool known = in && v == v;
+                if (__ballot(known && v <= dc) != 0ull) { hit = true; break; }      // mod.rs:333-335
+                const unsigned long long um = __ballot(in && !known);
+                if (in && !known) { const uint32_t at = nmiss + (uint32_t)__popcll(um & ((1ull << lane) - 1ull)); MID[at] = SEL[k]; MH[at] = SELH[k]; }
+                nmiss += (uint32_t)__popcll(um);
+            }
+            F_WSYNC();
+            if (!hit && nmiss) {                                                    // the rest is evaluated, in R's order, FUSED_RB rows at a time, until one is close enough
+                f_park_w(fp, p.rows + (size_t)LID[c] * p.pitch, lane, QV);
+                for (uint32_t j0 = 0; j0 < nmiss; j0 += B) {
+                    const uint32_t nb = nmiss - j0 < B ? nmiss - j0 : B;
+                    const float d = f_dist_batch<OP, LPR>(fp, QV, MID + j0, nb, lane);
+                    ndist += nb;
+                    if (lane < nb) M[bl_tri(hc, MH[j0 + lane])] = d;
+                    if (__ballot(lane < nb && d <= dc) != 0ull) { hit = true; break; }
+                }
+            }
+            if (lane == 0) { if (!hit) { SEL[nR] = LID[c]; SELH[nR] = hc; RI[nR] = c; } else DI[nD] = c; }
+            if (!hit) nR++; else nD++;
+            F_WSYNC();
+        }
+        for (uint32_t k = 0; k < nD && nR < lm; k++, nR++) if (lane == 0) RI[nR] = DI[k];   // mod.rs:300-305
         F_WSYNC();
-        for (uint32_t i = lane; i < nR; i += 64) { LID[i] = TI[i]; LD[i] = TD[i]; }      // mod.rs:484-485
+        for (uint32_t i = lane; i < nR; i += 64) { const uint32_t c = RI[i]; TI[i] = LID[c]; TD[i] = LD[c]; TH[i] = HND[c]; USED[c] = 1u; }
+        F_WSYNC();
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {                                   // the one candidate left out hands its handle on
+            const unsigned long long out = __ballot(c0 + lane < n && USED[c0 + lane < n ? c0 + lane : 0] == 0u);
+            if (out) { hfree = HND[c0 + (uint32_t)__builtin_ctzll(out)]; break; }
+        }
+        hfree = (uint32_t)__builtin_amdgcn_readfirstlane((int)hfree);
+        F_WSYNC();
+        for (uint32_t i = lane; i < nR; i += 64) { LID[i] = TI[i]; LD[i] = TD[i]; HND[i] = TH[i]; }   // mod.rs:484-485
         cnt = nR;
         F_WSYNC();
     }
@@ -200,9 +256,18 @@ static hipError_t launch_list_ops(hx_engine *e, const ListOpsParams &p, bool dis
         else hipLaunchKernelGGL((k_update_runs_big<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
         return hipGetLastError();
     }
-    if (e->pitch <= 128) hipLaunchKernelGGL((k_list_ops<OP, 8>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
-    else if (e->pitch <= 512) hipLaunchKernelGGL((k_list_ops<OP, 32>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
-    else hipLaunchKernelGGL((k_list_ops<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+    const size_t ldm = (14 * BL_MAX + 64) * 4 + nch * 1024 + ((size_t)p.lm0 + 1) * p.lm0 / 2 * 4;   // + the pair memo
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t st = hipFuncSetAttribute((const void *)k_list_ops<OP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (st == hipSuccess) st = hipFuncSetAttribute((const void *)k_list_ops<OP, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (st == hipSuccess) st = hipFuncSetAttribute((const void *)k_list_ops<OP, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (st != hipSuccess) return st;
+        attr_set = true;
+    }
+    if (e->pitch <= 128) hipLaunchKernelGGL((k_list_ops<OP, 8>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
+    else if (e->pitch <= 512) hipLaunchKernelGGL((k_list_ops<OP, 32>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
+    else hipLaunchKernelGGL((k_list_ops<OP, 64>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
     return hipGetLastError();
 }
 
