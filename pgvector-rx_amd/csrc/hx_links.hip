@@ -641,17 +641,26 @@ k_update_runs(const UpdRunParams p)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint32_t *LID = (uint32_t *)lds; float *LD = (float *)(LID + 64);
     uint32_t *ORD = (uint32_t *)(LD + 64);
-    uint32_t *SEL = ORD + 72, *PRN = SEL + 64;
-    float *DSC = (float *)(PRN + 64);
+    uint32_t *SEL = ORD + 72, *SELS = SEL + 64, *PRN = SELS + 64, *MID = PRN + 64, *MS = MID + 64;   // kept members: row ids, slots; pruned slots; members whose pair is not in the memo yet
+    float *DSC = (float *)(MS + 64);
     lds_u8 *QV = (lds_u8 *)(DSC + 64);
+    const uint32_t nch = (p.pitch + 1023u) / 1024u;
+    // pair memo of the run: M[tri(slot a, slot b)] = d(member a, member b) once the walk has asked for it, NaN before; a replaced slot forgets its row.
+    // (pairs with the new element are never evaluated, insert.rs:680-693, so slots are all the key there is)
+    float *M = (float *)((uint8_t *)QV + nch * 1024u);
     const uint32_t lane = threadIdx.x, r = blockIdx.x;
     if (r >= p.n_runs) return;
-    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC};
+    const FRows fp{p.rows, p.pitch, nch, DSC};
     const uint32_t lm = p.lm[r];
     uint32_t cnt = p.cnt[r];
     if (lane < cnt) { LID[lane] = p.ids[(size_t)r * p.stride + lane]; LD[lane] = p.d[(size_t)r * p.stride + lane]; }
+    const float qnan = __builtin_nanf("");
+    const bool memo = p.op_off[r + 1] - p.op_off[r] > 1u;                           // a single op has nothing to remember for
+    if (memo) for (uint32_t i = lane; i < lm * (lm - 1u) / 2u; i += 64) M[i] = qnan;
     F_WSYNC();
     unsigned long long ndist = 0;
+    constexpr uint32_t B = f_step_rows<LPR>();
+    auto tri = [](uint32_t a, uint32_t b) { const uint32_t hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi - 1u) / 2u + lo; };
     for (uint32_t op = p.op_off[r]; op < p.op_off[r + 1]; op++) {
         const uint32_t nid = p.op_new[op]; const float nd = p.op_d[op];
         if (__ballot(lane < cnt && LID[lane] == nid) != 0ull) continue;             // connection already exists
@@ -668,19 +677,44 @@ k_update_runs(const UpdRunParams p)
             if (nsel >= lm) break;
             const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)ORD[h]);
             if (s == 64u) { new_sel = true; nsel++; continue; }
+            const float ds = LD[s];
             bool hit = false;
             if (nselm) {
-                f_park_w(fp, p.rows + (size_t)LID[s] * p.pitch, lane, QV);
-                hit = f_any_le<OP, LPR>(fp, QV, SEL, nselm, lane, LD[s], ndist);
+                uint32_t nmiss = nselm;
+                if (memo) {                                                         // what the run already knows about member s
+                    const bool in = lane < nselm;
+                    const float v = in ? M[tri(s, SELS[lane])] : 0.0f;
+                    const bool known = in && v == v;
+                    hit = __ballot(known && v <= ds) != 0ull;
+                    const unsigned long long um = __ballot(in && !known);
+                    if (in && !known) { const uint32_t at = (uint32_t)__popcll(um & ((1ull << lane) - 1ull)); MID[at] = SEL[lane]; MS[at] = SELS[lane]; }
+                    nmiss = (uint32_t)__popcll(um);
+                    F_WSYNC();
+                }
+                if (!hit && nmiss) {
+                    const uint32_t *ids = memo ? MID : SEL;
+                    f_park_w(fp, p.rows + (size_t)LID[s] * p.pitch, lane, QV);
+                    for (uint32_t j0 = 0; j0 < nmiss; j0 += B) {
+                        const uint32_t nb = nmiss - j0 < B ? nmiss - j0 : B;
+                        const float d = f_dist_batch<OP, LPR>(fp, QV, ids + j0, nb, lane);
+                        ndist += nb;
+                        if (memo && lane < nb) M[tri(s, MS[j0 + lane])] = d;
+                        if (__ballot(lane < nb && d <= ds) != 0ull) { hit = true; break; }
+                    }
+                }
             }
-            if (!hit) { if (lane == 0) SEL[nselm] = LID[s]; nselm++; nsel++; if (lane == s) kept = true; }
+            if (!hit) { if (lane == 0) { SEL[nselm] = LID[s]; SELS[nselm] = s; } nselm++; nsel++; if (lane == s) kept = true; }
             else { if (lane == 0) PRN[npr] = s; npr++; }
             F_WSYNC();
         }
         for (uint32_t k = 0; k < npr && nsel < lm; k++, nsel++) if (lane == PRN[k]) kept = true;
         if (new_sel) {
             const unsigned long long out = __ballot(lane < cnt && !kept);
-            if (out) { const uint32_t slot = (uint32_t)__builtin_ctzll(out); if (lane == 0) { LID[slot] = nid; LD[slot] = nd; } }
+            if (out) {
+                const uint32_t slot = (uint32_t)__builtin_ctzll(out);
+                if (lane == 0) { LID[slot] = nid; LD[slot] = nd; }
+                if (memo && lane < cnt && lane != slot) M[tri(slot, lane)] = qnan;  // the slot's previous owner is gone
+            }
         }
         F_WSYNC();
     }
@@ -692,7 +726,7 @@ template <class OP>
 static hipError_t launch_update_runs(hx_engine *e, const UpdRunParams &p)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
-    const size_t lds = (64 * 5 + 72) * 4 + nch * 1024;
+    const size_t lds = (64 * 8 + 72) * 4 + nch * 1024 + (size_t)p.stride * (p.stride - 1) / 2 * 4;   // + the run's pair memo
     if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs<OP, 8>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
     else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_runs<OP, 32>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
     else hipLaunchKernelGGL((k_update_runs<OP, 64>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
