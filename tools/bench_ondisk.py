@@ -13,7 +13,7 @@ ins = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 dim = int(sys.argv[3]) if len(sys.argv) > 3 else 768
 m, efc = 16, 64
 for b in (10, 256, 2048, 8192):
-    n = base + ins + b
+    n = base + ins + 2 * b
     rows, _ = bench.synth(n, dim, "gmm", 1, "cuda")
     e = hx.Engine(hx.F32, hx.L2SQ, dim, n); e.append_device(rows.data_ptr(), n)
     ix = hx.Index(e, m, efc)
@@ -28,4 +28,15 @@ for b in (10, 256, 2048, 8192):
                       "lock_step_rounds": pr["rounds"], "fused_s": round(pr["fused_s"], 4), "round_s": round(pr["round_s"], 4), "advance_s": round(pr["advance_s"], 4),
                       "mirror_sync_s": round(pr["mirror_sync_s"], 4), "members_s": round(pr["links_setup_s"], 4), "updates_s": round(pr["links_lockstep_s"], 4),
                       "total_s": round(pr["insert_total_s"], 4)}), flush=True)
+    if b == 2048:                                                                   # VACUUM of every 10th heap TID of the same index: the three passes, repairs `b` at a time
+        size = ix.size
+        dead = np.arange(0, size, 10, dtype=np.int64)
+        f0 = ix.fused_stats(); ix.profile(reset=True)
+        t0 = time.perf_counter(); nd, nr = ix.vacuum(dead, batch=b); dt = time.perf_counter() - t0
+        f1 = ix.fused_stats(); pr = ix.profile()
+        print(json.dumps({"vacuum_of_rows": int(len(dead)), "index_rows": int(size), "deleted": int(nd), "repaired": int(nr), "seconds": round(dt, 3), "repairs_per_s": round(nr / dt, 1),
+                          "repair_batch": b, "device_repair_searches": int(f1["tasks"] - f0["tasks"]), "handed_to_lock_step": int(f1["redone"] - f0["redone"]),
+                          "lock_step_rounds": pr["rounds"], "fused_s": round(pr["fused_s"], 4)}), flush=True)
+        t0 = time.perf_counter(); ix.insert_ondisk(size, levels[size:size + b], tids=np.arange(size, size + b), batch=b); dt = time.perf_counter() - t0
+        print(json.dumps({"after_vacuum": True, "concurrent_inserts": b, "rows": b, "rows_per_s": round(b / dt, 1)}), flush=True)
     ix.close(); e.close(); del rows
