@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t bl_select(const FRows &fp, lds_u8 *QV, uint3
 }
 
 struct SelWParams {
-    const uint8_t *rows; uint32_t pitch, cap, n_prob, stride, lm0;                 // cap: 0 (dense rows only -- sparsevec lists stay on the lock-step driver's merge-join pair kernels, which measured faster: one lane per row leaves a one-wave-per-list kernel mostly idle)
+    const uint8_t *rows; uint32_t pitch, cap, n_prob, stride, lm0;                 // cap: sparsevec records' entry capacity (0: dense rows)
     const uint2 *wl; const uint32_t *wl_cnt, *lm;                                   // W of problem pr: wl[pr * stride ..), ascending, {distance bits, id}
     uint32_t *out_ids; float *out_d; uint32_t *out_cnt; unsigned long long *n_pairs;
 };
@@ -105,7 +105,7 @@ k_list_ops(const ListOpsParams p)
     uint32_t hfree = lm;                                                            // the handle no list position holds once the list is full
     F_WSYNC();
     unsigned long long ndist = 0;
-    constexpr uint32_t B = f_step_rows<LPR>();
+    constexpr uint32_t B = OP::kSparse ? 64u : f_step_rows<LPR>();               // sparsevec: one lane per row, so a step holds a lane-full of rows
     for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
         if (cnt < lm) {                                                             // mod.rs:469-471
             if (lane == 0) { LID[cnt] = p.op_new[op]; LD[cnt] = p.op_d[op]; HND[cnt] = cnt; }
@@ -240,7 +240,8 @@ static hipError_t launch_select_w(hx_engine *e, const SelWParams &p)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
     const size_t lds = (2 * BL_MAX + ((p.stride + 15u) & ~15u) + 64) * 4 + nch * 1024;
-    if (e->pitch <= 128) hipLaunchKernelGGL((k_select_w<OP, 8>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
+    if constexpr (OP::kSparse) hipLaunchKernelGGL((k_select_w<OP, 64>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
+    else if (e->pitch <= 128) hipLaunchKernelGGL((k_select_w<OP, 8>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
     else if (e->pitch <= 512) hipLaunchKernelGGL((k_select_w<OP, 32>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
     else hipLaunchKernelGGL((k_select_w<OP, 64>), dim3(p.n_prob), dim3(64), lds, e->stream, p);
     return hipGetLastError();
@@ -251,7 +252,8 @@ static hipError_t launch_list_ops(hx_engine *e, const ListOpsParams &p, bool dis
     const size_t nch = (e->pitch + 1023) / 1024;
     const size_t lds = (8 * BL_MAX + 64) * 4 + nch * 1024;
     if (disk) {
-        if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs_big<OP, 8>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
+        if constexpr (OP::kSparse) return hipErrorInvalidValue;                       // aminsert's back-connections on sparsevec rows: lock-step driver
+        else if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs_big<OP, 8>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
         else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_runs_big<OP, 32>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
         else hipLaunchKernelGGL((k_update_runs_big<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
         return hipGetLastError();
@@ -259,13 +261,16 @@ static hipError_t launch_list_ops(hx_engine *e, const ListOpsParams &p, bool dis
     const size_t ldm = (14 * BL_MAX + 64) * 4 + nch * 1024 + ((size_t)p.lm0 + 1) * p.lm0 / 2 * 4;   // + the pair memo
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        hipError_t st = hipFuncSetAttribute((const void *)k_list_ops<OP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        if (st == hipSuccess) st = hipFuncSetAttribute((const void *)k_list_ops<OP, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        if (st == hipSuccess) st = hipFuncSetAttribute((const void *)k_list_ops<OP, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        hipError_t st = hipFuncSetAttribute((const void *)k_list_ops<OP, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if constexpr (!OP::kSparse) {
+            if (st == hipSuccess) st = hipFuncSetAttribute((const void *)k_list_ops<OP, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            if (st == hipSuccess) st = hipFuncSetAttribute((const void *)k_list_ops<OP, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        }
         if (st != hipSuccess) return st;
         attr_set = true;
     }
-    if (e->pitch <= 128) hipLaunchKernelGGL((k_list_ops<OP, 8>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
+    if constexpr (OP::kSparse) hipLaunchKernelGGL((k_list_ops<OP, 64>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
+    else if (e->pitch <= 128) hipLaunchKernelGGL((k_list_ops<OP, 8>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
     else if (e->pitch <= 512) hipLaunchKernelGGL((k_list_ops<OP, 32>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
     else hipLaunchKernelGGL((k_list_ops<OP, 64>), dim3(p.n_groups), dim3(64), ldm, e->stream, p);
     return hipGetLastError();
@@ -293,7 +298,7 @@ int hx_engine::biglist_select(uint32_t n_prob, uint32_t stride, const uint32_t *
 {
     if (n_prob == 0) return HX_OK;
     if (lm0 == 0 || lm0 > 200 || stride == 0 || stride > 1000) return fail(HX_E_ARG, "biglist_select: list size / ef_construction out of range");
-    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_select_w serves dense rows <= 8 KiB");
+    if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_select_w serves rows <= 8 KiB");
     if (!wsel.d_wl || n_prob > wsel.cap_prob || stride > wsel.cap_ef) return fail(HX_E_STATE, "biglist_select: no result sets on the device");
     HX_HIP(this, hipSetDevice(device));
     size_t o = 64;
@@ -309,7 +314,7 @@ int hx_engine::biglist_select(uint32_t n_prob, uint32_t stride, const uint32_t *
     memcpy(mr.h_lk + o_lm, lm, (size_t)n_prob * 4);
     HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, in_bytes, hipMemcpyHostToDevice, stream));
     SelWParams p;
-    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = 0u; p.n_prob = n_prob; p.stride = stride; p.lm0 = lm0;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = dtype == HX_SPARSE ? (uint32_t)std::min(dim, HX_SPARSE_MAX_NNZ) : 0u; p.n_prob = n_prob; p.stride = stride; p.lm0 = lm0;
     p.wl = (const uint2 *)wsel.d_wl; p.wl_cnt = wsel.d_cnt; p.lm = (const uint32_t *)(mr.d_lk + o_lm);
     p.out_ids = (uint32_t *)(mr.d_lk + o_ids); p.out_d = (float *)(mr.d_lk + o_d); p.out_cnt = (uint32_t *)(mr.d_lk + o_cnt);
     p.n_pairs = (unsigned long long *)mr.d_lk;
@@ -317,7 +322,8 @@ int hx_engine::biglist_select(uint32_t n_prob, uint32_t stride, const uint32_t *
     hipError_t ls = hipSuccess;
 #define F32C(K) ls = launch_select_w<OpF32<K>>(this, p)
 #define F16C(K) ls = launch_select_w<OpF16<K>>(this, p)
-    HX_DISPATCH(this, F32C, F16C, ls = launch_select_w<OpHamming>(this, p), ls = launch_select_w<OpJaccard>(this, p));
+    if (dtype == HX_SPARSE) ls = metric == HX_L2SQ ? launch_select_w<OpSparse<K_L2>>(this, p) : metric == HX_NEG_IP ? launch_select_w<OpSparse<K_IP>>(this, p) : launch_select_w<OpSparse<K_L1>>(this, p);
+    else HX_DISPATCH(this, F32C, F16C, ls = launch_select_w<OpHamming>(this, p), ls = launch_select_w<OpJaccard>(this, p));
 #undef F32C
 #undef F16C
     HX_HIP(this, ls);
@@ -338,7 +344,7 @@ int hx_engine::biglist_ops_stage(uint32_t n_groups, uint32_t n_ops, uint32_t lm0
                                  uint32_t **op_new, float **op_d)
 {
     if (n_groups == 0 || lm0 == 0 || lm0 > 200) return fail(HX_E_ARG, "biglist_ops_stage: bad sizes");
-    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_list_ops serves dense rows <= 8 KiB");
+    if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_list_ops serves rows <= 8 KiB");
     HX_HIP(this, hipSetDevice(device));
     size_t o = 64;
     bl_o_lm = o; o += al16((size_t)n_groups * 4);
@@ -366,7 +372,7 @@ int hx_engine::biglist_ops_run(uint64_t *n_pairs, bool disk)
     HX_HIP(this, hipSetDevice(device));
     HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, bl_end, hipMemcpyHostToDevice, stream));
     ListOpsParams p;
-    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = 0u; p.n_groups = bl_groups; p.lm0 = bl_lm0;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = dtype == HX_SPARSE ? (uint32_t)std::min(dim, HX_SPARSE_MAX_NNZ) : 0u; p.n_groups = bl_groups; p.lm0 = bl_lm0;
     p.ids = (uint32_t *)(mr.d_lk + bl_o_ids); p.d = (float *)(mr.d_lk + bl_o_d); p.cnt = (uint32_t *)(mr.d_lk + bl_o_cnt);
     p.lm = (const uint32_t *)(mr.d_lk + bl_o_lm); p.op_off = (const uint32_t *)(mr.d_lk + bl_o_off); p.op_new = (const uint32_t *)(mr.d_lk + bl_o_new);
     p.op_d = (const float *)(mr.d_lk + bl_o_od); p.n_pairs = (unsigned long long *)mr.d_lk;
@@ -374,7 +380,8 @@ int hx_engine::biglist_ops_run(uint64_t *n_pairs, bool disk)
     hipError_t ls = hipSuccess;
 #define F32C(K) ls = launch_list_ops<OpF32<K>>(this, p, disk)
 #define F16C(K) ls = launch_list_ops<OpF16<K>>(this, p, disk)
-    HX_DISPATCH(this, F32C, F16C, ls = launch_list_ops<OpHamming>(this, p, disk), ls = launch_list_ops<OpJaccard>(this, p, disk));
+    if (dtype == HX_SPARSE) ls = metric == HX_L2SQ ? launch_list_ops<OpSparse<K_L2>>(this, p, disk) : metric == HX_NEG_IP ? launch_list_ops<OpSparse<K_IP>>(this, p, disk) : launch_list_ops<OpSparse<K_L1>>(this, p, disk);
+    else HX_DISPATCH(this, F32C, F16C, ls = launch_list_ops<OpHamming>(this, p, disk), ls = launch_list_ops<OpJaccard>(this, p, disk));
 #undef F32C
 #undef F16C
     HX_HIP(this, ls);

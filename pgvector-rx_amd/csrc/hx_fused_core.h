@@ -507,7 +507,7 @@ template <class OP, int LPR>
 __device__ __forceinline__ bool f_any_le(const FRows &p, const lds_u8 *qv, const uint32_t *ids, uint32_t n, uint32_t lane, float thr,
                                          unsigned long long &n_eval)
 {
-    constexpr uint32_t B = f_step_rows<LPR>();
+    constexpr uint32_t B = OP::kSparse ? 64u : f_step_rows<LPR>();   // sparsevec: one lane per row, so a step holds a lane-full of rows
     for (uint32_t j0 = 0; j0 < n; j0 += B) {
         const uint32_t nb = n - j0 < B ? n - j0 : B;
         const float d = f_dist_batch<OP, LPR>(p, qv, ids + j0, nb, lane);

@@ -825,7 +825,7 @@ struct hx_index {
     std::string err;
     int fail(int code, const std::string &m) { err = m; return code; }
 
-    bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192 && e->dtype != HX_SPARSE; }   // sparsevec: lock-step driver (merge-join kernels)
+    bool fused_ok() const { return fused && 2 * g.m <= 64 && e->pitch <= 8192 && e->dtype != HX_SPARSE; }   // the insert kernel / batch pipeline; sparsevec and m > 32: MODE 3 + hx_biglist.hip
     // scans: the traversal kernel walks lists longer than a wavefront 64 ids at a time, so every m the reference allows (options.rs:203-225: m <= 100) is served;
     // only the insert-mode kernel and the back-link kernels are built for lists of <= 64
     bool fused_scan_ok() const { return fused && e->pitch <= 8192; }   // round 3: sparsevec too (hx_fused_sparse.hip: one lane per row walks the merge join)
@@ -1187,7 +1187,7 @@ int hx_index_batch_search(hx_index *ix, uint32_t lo, uint32_t hi)
         ix->prof[6] += hx_index::now_s() - t0;
         ix->counters[1] += cnts[0];
         static const bool biglist_off = getenv("HX_BIGLIST") && atoi(getenv("HX_BIGLIST")) == 0;     // experiments: select / back-links of these shapes on the lock-step driver
-        if (!biglist_off && e->dtype != HX_SPARSE) {
+        if (!biglist_off) {
             // select_neighbors per (member, layer) in k_select_w (hx_biglist.hip), straight from the result sets the traversal kernel left on the device
             const uint32_t lm0 = 2u * (uint32_t)g.m;
             std::vector<uint32_t> lmv(P, lm0);
@@ -1483,8 +1483,8 @@ int hx_index_batch_links(hx_index *ix, uint32_t rank, uint32_t world)
         return HX_OK;
     }
     static const bool biglist_off = getenv("HX_BIGLIST") && atoi(getenv("HX_BIGLIST")) == 0;
-    if (ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192 && !biglist_off) {
-        // lists the lane-per-slot kernels do not serve (m > 32: up to 200 slots): k_list_ops (hx_biglist.hip), one wavefront per owned list, from the
+    if (ix->fused && ix->e->pitch <= 8192 && !biglist_off) {
+        // lists the lane-per-slot kernels do not serve (m > 32: up to 200 slots; sparsevec rows): k_list_ops (hx_biglist.hip), one wavefront per owned list, from the
         // list contents the host hands over; the new lists come back into the host copy (the master for these index shapes)
         auto &own = ix->ls.own; own.clear();
         for (uint32_t gi = 0; gi < bs.grp.size(); gi++) if (ops[bs.grp[gi].first].target % world == rank) own.push_back(gi);

@@ -98,7 +98,7 @@ def test_sparse_index_equals_oracle(metric, cosine, fused):
     """Build + scan of an HNSW index on sparsevec rows (sparsevec_l2_ops / _ip_ops / _l1_ops / _cosine_ops, sparsevec.rs:1552-1582): graph and
     top-k identical to the oracle's; the reference's own 4-row orderings (tests/pg_regress/expected/hnsw_sparsevec.out) are pinned on the oracle
     in tests/test_oracle_golden.py.  Round 3: the searches of the build and the scans run in the traversal kernel (hx_fused_sparse.hip: one lane per
-    row walks the merge join); `lock-step` is the round-2 placement on the merge-join kernels."""
+    row walks the merge join), select_neighbors and the back-links in k_select_w / k_list_ops (hx_biglist.hip); `lock-step` is the round-2 placement on the merge-join kernels."""
     rng = np.random.default_rng(11 + metric + cosine)
     dim, n, m, efc = 400, 600, 8, 40
     rows = random_sparse(rng, n, dim, 30)
@@ -148,6 +148,8 @@ def test_sparse_index_equals_oracle(metric, cosine, fused):
         assert (d[q, :cnt[q]].view(np.uint32) == np.array([y for _, y, _ in res], np.float32).view(np.uint32)).all()
     st = ix.fused_stats()
     assert (st["tasks"] >= nk and st["redone"] == 0) if fused else st["tasks"] == 0    # the searches were device tasks / the lock-step driver on the merge-join kernels
+    if fused:
+        assert ix.profile()["rounds"] == 0                                          # select_neighbors and the back-links too (hx_biglist.hip: k_select_w, k_list_ops)
     # iterative scans (relaxed and strict order) on the same placement
     for mode in (1, 2):
         ti, di, ci = ix.search_iterative(12, 10, mode, 200, 15)

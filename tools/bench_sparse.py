@@ -1,5 +1,5 @@
-"""sparsevec on the engine: build + scan timing on one MI355X (round 3: searches and scans in the traversal kernel, hx_fused_sparse.hip; select and back-links on the
-lock-step driver over the merge-join kernels of csrc/hx_sparse.hip).
+"""sparsevec on the engine: build + scan timing on one MI355X (round 3: searches and scans in the traversal kernel, hx_fused_sparse.hip; select and back-links in the
+list kernels of csrc/hx_biglist.hip; hx_index_set_fused(0): the lock-step driver over the merge-join kernels of csrc/hx_sparse.hip).
 python tools/bench_sparse.py [rows] [dim] [max_nnz]"""
 import json, sys, time
 import numpy as np
@@ -27,7 +27,9 @@ e = hx.Engine(hx.SPARSE, hx.NEG_IP, dim, n)
 e.append(rec)
 e.normalize_rows(0, n)
 ix = hx.Index(e, m, efc)
+ix.profile(reset=True)
 t0 = time.perf_counter(); ix.insert(0, hx.draw_levels(n, m, seed=1), batch=4096); build = time.perf_counter() - t0
+pr = ix.profile(); cn = ix.counters()
 e.set_queries(qrec, normalize=True)
 ix.search(nq, efs, k)
 t0 = time.perf_counter(); tids, d, el, cnt = ix.search(nq, efs, k); dt = time.perf_counter() - t0
@@ -39,4 +41,5 @@ for q in range(64):
     top = set(np.argsort(dq, kind="stable")[:k].tolist())
     hits += len(top & set(tids[q, :cnt[q]].tolist()))
 print(json.dumps({"rows": n, "dim": dim, "max_nnz": mx, "record_bytes": int(rec.shape[1]), "metric": "cosine (normalised, negative inner product)", "m": m, "ef_construction": efc,
-                  "build_sec": round(build, 2), "qps": round(nq / dt, 1), "ef_search": efs, "recall_at_10": round(hits / (64 * k), 4), "path": "traversal kernel (k_fused<OpSparse>: scans, build searches); select + back-links: lock-step driver over k_sparse_pairs" if ix.fused_stats()["tasks"] else "lock-step driver, k_sparse_groups / k_sparse_pairs"}))
+                  "build_sec": round(build, 2), "build_profile": {k2: (round(v, 3) if isinstance(v, float) else v) for k2, v in pr.items()},
+                  "build_distance_evals": {"search": int(cn[1]), "select": int(cn[2]), "backlink": int(cn[3])}, "qps": round(nq / dt, 1), "ef_search": efs, "recall_at_10": round(hits / (64 * k), 4), "path": "traversal kernel (k_fused<OpSparse>: scans, build searches); select + back-links: k_select_w / k_list_ops (hx_biglist.hip)" if ix.fused_stats()["tasks"] else "lock-step driver, k_sparse_groups / k_sparse_pairs"}))
