@@ -1,6 +1,6 @@
 // hx_fused_sparse.hip -- k_fused instantiations for sparsevec rows (see hx_fused_kernel.h; the distance path is f_dist_batch's OpSparse branch).
 // Scans (MODE 0, 2) and search-only inserts (MODE 3: builds and aminsert; select_neighbors and the back-links of a build follow in hx_biglist.hip's
-// list kernels, aminsert's back-connections on the lock-step driver, whose pair kernels walk the merge joins).  One wavefront per search, one LANE per row of an expansion; always the 64-lanes-per-task build.
+// list kernels, aminsert's back-connections in hx_links.hip's k_update_runs; hx_index_set_fused(0): the lock-step driver, whose pair kernels walk the merge joins).  One wavefront per search, one LANE per row of an expansion; always the 64-lanes-per-task build.
 #include "hx_fused_kernel.h"
 
 template <int KIND>

@@ -1941,7 +1941,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
     const bool big = 2 * g.m > (int)HX_PAIR_MAX_ROWS;                               // lists of more than 64 slots: device kernels only (hx_biglist.hip)
     if (big && !(ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192))
-        return ix->fail(HX_E_ARG, "m > 32: the on-disk insert path runs in the device kernels only (dense rows <= 8 KiB, hx_index_set_fused(1))");
+        return ix->fail(HX_E_ARG, "m > 32: the on-disk insert path runs in the device kernels only (dense rows <= 8 KiB, hx_index_set_fused(1))");   // (k_update_runs_big: dense operators)
     if (batch == 0) batch = 1;
     hx_index::Timer t_all(ix->prof[10]);
     int rc = ix->ensure_host_lists();
@@ -2083,7 +2083,7 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
             auto &uts = ix->update_pool;
             // Device placement of a wave (round 3): the host settles what needs no distance (insert.rs:524-527, 556-559, 566-625) and k_update_index
             // (hx_links.hip) answers the full lists, one wavefront per op, from the list contents the host hands over.
-            const bool dev_upd = ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192;
+            const bool dev_upd = ix->fused && ix->e->pitch <= 8192;
             std::vector<uint32_t> wops, devq; std::vector<int> wres;
             // no deleted / TID-less element in the index: get_update_index's early exits cannot fire, and k_update_runs applies a list's whole run in one go
             bool runs_done = false;

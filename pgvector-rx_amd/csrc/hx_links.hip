@@ -575,7 +575,7 @@ k_links_hub(const LinksParams p, float *pm, uint8_t *pm_valid)
 //   when the walk asks for them (the lock-step driver orders all lm (lm - 1) / 2 up front); the answer is the same.
 // =================================================================================================
 struct UpdParams {
-    const uint8_t *rows; uint32_t pitch, n_ops, stride;
+    const uint8_t *rows; uint32_t pitch, cap, n_ops, stride;                       // cap: sparsevec records' entry capacity (0: dense rows)
     const uint32_t *ids; const float *d; const float *new_d; const uint32_t *cnt;
     int32_t *slot; unsigned long long *n_pairs;
 };
@@ -592,7 +592,7 @@ k_update_index(const UpdParams p)
     lds_u8 *QV = (lds_u8 *)(DSC + 64);
     const uint32_t lane = threadIdx.x, op = blockIdx.x;
     if (op >= p.n_ops) return;
-    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC};
+    const FRows fp{p.rows, p.pitch, (p.pitch + 1023u) / 1024u, DSC, p.cap};
     const uint32_t cnt = p.cnt[op], lm = cnt;                   // full list
     const float nd = p.new_d[op];
     float di = 0.0f;
@@ -629,7 +629,7 @@ k_update_index(const UpdParams p)
 // test (insert.rs:805-812), the free slot (:556-559, :826-838) and k_update_index's walk for a full list, the list kept in LDS between the ops.  For indexes
 // without deleted / TID-less elements (get_update_index's other exits, insert.rs:524-527, 566-625, never fire there); the new list goes back to the host.
 struct UpdRunParams {
-    const uint8_t *rows; uint32_t pitch, n_runs, stride;
+    const uint8_t *rows; uint32_t pitch, cap, n_runs, stride;
     uint32_t *ids; float *d; uint32_t *cnt;                       // list of run r: ids/d[r * stride ..), cnt[r]  (in and out)
     const uint32_t *lm, *op_off, *op_new; const float *op_d; unsigned long long *n_pairs;
 };
@@ -650,7 +650,7 @@ k_update_runs(const UpdRunParams p)
     float *M = (float *)((uint8_t *)QV + nch * 1024u);
     const uint32_t lane = threadIdx.x, r = blockIdx.x;
     if (r >= p.n_runs) return;
-    const FRows fp{p.rows, p.pitch, nch, DSC};
+    const FRows fp{p.rows, p.pitch, nch, DSC, p.cap};
     const uint32_t lm = p.lm[r];
     uint32_t cnt = p.cnt[r];
     if (lane < cnt) { LID[lane] = p.ids[(size_t)r * p.stride + lane]; LD[lane] = p.d[(size_t)r * p.stride + lane]; }
@@ -659,7 +659,7 @@ k_update_runs(const UpdRunParams p)
     if (memo) for (uint32_t i = lane; i < lm * (lm - 1u) / 2u; i += 64) M[i] = qnan;
     F_WSYNC();
     unsigned long long ndist = 0;
-    constexpr uint32_t B = f_step_rows<LPR>();
+    constexpr uint32_t B = OP::kSparse ? 64u : f_step_rows<LPR>();               // sparsevec: one lane per row, so a step holds a lane-full of rows
     auto tri = [](uint32_t a, uint32_t b) { const uint32_t hi = a > b ? a : b, lo = a > b ? b : a; return hi * (hi - 1u) / 2u + lo; };
     for (uint32_t op = p.op_off[r]; op < p.op_off[r + 1]; op++) {
         const uint32_t nid = p.op_new[op]; const float nd = p.op_d[op];
@@ -727,7 +727,8 @@ static hipError_t launch_update_runs(hx_engine *e, const UpdRunParams &p)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
     const size_t lds = (64 * 8 + 72) * 4 + nch * 1024 + (size_t)p.stride * (p.stride - 1) / 2 * 4;   // + the run's pair memo
-    if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs<OP, 8>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
+    if constexpr (OP::kSparse) hipLaunchKernelGGL((k_update_runs<OP, 64>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
+    else if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs<OP, 8>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
     else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_runs<OP, 32>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
     else hipLaunchKernelGGL((k_update_runs<OP, 64>), dim3(p.n_runs), dim3(64), lds, e->stream, p);
     return hipGetLastError();
@@ -738,7 +739,7 @@ int hx_engine::update_runs_stage(uint32_t n_runs, uint32_t n_ops, uint32_t strid
 {
     HxMirror &mr = mirror;
     if (n_runs == 0 || stride == 0 || stride > 64) return fail(HX_E_ARG, "update_runs_stage: bad sizes");
-    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_update_runs serves dense rows <= 8 KiB");
+    if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_update_runs serves rows <= 8 KiB");
     HX_HIP(this, hipSetDevice(device));
     size_t o = 64;
     ur_o_lm = o; o += al16((size_t)n_runs * 4);
@@ -774,7 +775,7 @@ int hx_engine::update_runs_run(uint64_t *n_pairs)
     HX_HIP(this, hipSetDevice(device));
     HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, ur_end, hipMemcpyHostToDevice, stream));
     UpdRunParams p;
-    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.n_runs = ur_n; p.stride = ur_stride;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = dtype == HX_SPARSE ? (uint32_t)std::min(dim, HX_SPARSE_MAX_NNZ) : 0u; p.n_runs = ur_n; p.stride = ur_stride;
     p.ids = (uint32_t *)(mr.d_lk + ur_o_ids); p.d = (float *)(mr.d_lk + ur_o_d); p.cnt = (uint32_t *)(mr.d_lk + ur_o_cnt);
     p.lm = (const uint32_t *)(mr.d_lk + ur_o_lm); p.op_off = (const uint32_t *)(mr.d_lk + ur_o_off); p.op_new = (const uint32_t *)(mr.d_lk + ur_o_new);
     p.op_d = (const float *)(mr.d_lk + ur_o_od); p.n_pairs = (unsigned long long *)mr.d_lk;
@@ -782,7 +783,8 @@ int hx_engine::update_runs_run(uint64_t *n_pairs)
     hipError_t ls = hipSuccess;
 #define F32C(K) ls = launch_update_runs<OpF32<K>>(this, p)
 #define F16C(K) ls = launch_update_runs<OpF16<K>>(this, p)
-    HX_DISPATCH(this, F32C, F16C, ls = launch_update_runs<OpHamming>(this, p), ls = launch_update_runs<OpJaccard>(this, p));
+    if (dtype == HX_SPARSE) ls = metric == HX_L2SQ ? launch_update_runs<OpSparse<K_L2>>(this, p) : metric == HX_NEG_IP ? launch_update_runs<OpSparse<K_IP>>(this, p) : launch_update_runs<OpSparse<K_L1>>(this, p);
+    else HX_DISPATCH(this, F32C, F16C, ls = launch_update_runs<OpHamming>(this, p), ls = launch_update_runs<OpJaccard>(this, p));
 #undef F32C
 #undef F16C
     HX_HIP(this, ls);
@@ -802,7 +804,8 @@ static hipError_t launch_update_index(hx_engine *e, const UpdParams &p)
 {
     const size_t nch = (e->pitch + 1023) / 1024;
     const size_t lds = (64 * 5 + 72) * 4 + nch * 1024;
-    if (e->pitch <= 128) hipLaunchKernelGGL((k_update_index<OP, 8>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
+    if constexpr (OP::kSparse) hipLaunchKernelGGL((k_update_index<OP, 64>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
+    else if (e->pitch <= 128) hipLaunchKernelGGL((k_update_index<OP, 8>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
     else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_index<OP, 32>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
     else hipLaunchKernelGGL((k_update_index<OP, 64>), dim3(p.n_ops), dim3(64), lds, e->stream, p);
     return hipGetLastError();
@@ -813,7 +816,7 @@ int hx_engine::update_index_stage(uint32_t n_ops, uint32_t stride, uint32_t **id
 {
     HxMirror &mr = mirror;
     if (n_ops == 0 || stride == 0 || stride > 64) return fail(HX_E_ARG, "update_index_stage: bad sizes");
-    if (dtype == HX_SPARSE || pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_update_index serves dense rows <= 8 KiB");
+    if (pitch > FUSED_MAXCH * 1024u) return fail(HX_E_STATE, "k_update_index serves rows <= 8 KiB");
     HX_HIP(this, hipSetDevice(device));
     size_t o = 64;
     ui_o_nd = o; o += al16((size_t)n_ops * 4);
@@ -846,14 +849,15 @@ int hx_engine::update_index_run(const int32_t **slot_out, uint64_t *n_pairs)
     HX_HIP(this, hipSetDevice(device));
     HX_HIP(this, hipMemcpyAsync(mr.d_lk, mr.h_lk, ui_in, hipMemcpyHostToDevice, stream));
     UpdParams p;
-    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.n_ops = ui_n; p.stride = ui_stride;
+    p.rows = d_rows; p.pitch = (uint32_t)pitch; p.cap = dtype == HX_SPARSE ? (uint32_t)std::min(dim, HX_SPARSE_MAX_NNZ) : 0u; p.n_ops = ui_n; p.stride = ui_stride;
     p.ids = (const uint32_t *)(mr.d_lk + ui_o_ids); p.d = (const float *)(mr.d_lk + ui_o_d); p.new_d = (const float *)(mr.d_lk + ui_o_nd);
     p.cnt = (const uint32_t *)(mr.d_lk + ui_o_cnt); p.slot = (int32_t *)(mr.d_lk + ui_o_slot); p.n_pairs = (unsigned long long *)mr.d_lk;
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
 #define F32C(K) ls = launch_update_index<OpF32<K>>(this, p)
 #define F16C(K) ls = launch_update_index<OpF16<K>>(this, p)
-    HX_DISPATCH(this, F32C, F16C, ls = launch_update_index<OpHamming>(this, p), ls = launch_update_index<OpJaccard>(this, p));
+    if (dtype == HX_SPARSE) ls = metric == HX_L2SQ ? launch_update_index<OpSparse<K_L2>>(this, p) : metric == HX_NEG_IP ? launch_update_index<OpSparse<K_IP>>(this, p) : launch_update_index<OpSparse<K_L1>>(this, p);
+    else HX_DISPATCH(this, F32C, F16C, ls = launch_update_index<OpHamming>(this, p), ls = launch_update_index<OpJaccard>(this, p));
 #undef F32C
 #undef F16C
     HX_HIP(this, ls);

@@ -260,7 +260,9 @@ def test_sparsevec_vacuum_insert_rounds_on_device():
         rec = hx.pack_sparse(dim, rows)
         e.append(rec)
         tids = np.arange(r * per + 1, r * per + per + 1, dtype=np.int64)
+        rounds_before = ix.profile()["rounds"]
         ix.insert_ondisk(r * per, levels[r * per:(r + 1) * per], tids=tids, batch=1)
+        assert ix.profile()["rounds"] - rounds_before <= 2 * per          # searches in k_fused<OpSparse>, back-connections in k_update_runs<OpSparse>: one kernel each per insert, no lock-step expansion rounds
         for i in range(per):
             o.insert_on_disk(rec[i], int(levels[r * per + i]), int(tids[i]))
         kill = np.asarray([t for t in range(1, (r + 1) * per + 1) if t % g["delete_mod"] == 0 and t not in dead], np.int64)
