@@ -73,6 +73,8 @@ struct ListOpsParams {
     const uint8_t *rows; uint32_t pitch, cap, n_groups, lm0;
     uint32_t *ids; float *d; uint32_t *cnt;                                         // list of group g: ids/d[g * lm0 ..), cnt[g]  (in and out)
     const uint32_t *lm, *op_off, *op_new; const float *op_d; unsigned long long *n_pairs;
+    // mirror mode (mir.l0_ids != nullptr): the lists are the device mirror's own (group g = (mir.target[g], mir.layer[g]), launch index -> group through mir.gmap)
+    ListMirrorArgs mir;
 };
 
 // Pair memo of k_list_ops: the candidates of one list carry HANDLES (0..lm; a list position keeps its handle while the element stays, the element a
@@ -94,26 +96,35 @@ k_list_ops(const ListOpsParams p)
     lds_u8 *QV = (lds_u8 *)(DSC + 64);
     const uint32_t nch = (p.pitch + 1023u) / 1024u;
     float *M = (float *)((uint8_t *)QV + nch * 1024u);                              // (lm0 + 1) lm0 / 2 entries
-    const uint32_t lane = threadIdx.x, g = blockIdx.x;
-    if (g >= p.n_groups) return;
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x >= p.n_groups) return;
+    const bool mirror = p.mir.l0_ids != nullptr;
+    const uint32_t g = mirror && p.mir.gmap ? p.mir.gmap[blockIdx.x] : blockIdx.x;
     const FRows fp{p.rows, p.pitch, nch, DSC, p.cap};
-    const uint32_t lm = p.lm[g];
-    uint32_t cnt = p.cnt[g];
-    for (uint32_t i = lane; i < cnt; i += 64) { LID[i] = p.ids[(size_t)g * p.lm0 + i]; LD[i] = p.d[(size_t)g * p.lm0 + i]; HND[i] = i; }
+    uint32_t *gl_ids; float *gl_d; uint16_t *gl_cnt16 = nullptr; uint32_t lm, cnt, target = 0, layer = 0;
+    if (mirror) {
+        target = p.mir.target[g]; layer = p.mir.layer[g];
+        lm = layer == 0 ? 2u * p.mir.m : p.mir.m;
+        if (layer == 0) { gl_ids = p.mir.l0_ids + (size_t)target * 2u * p.mir.m; gl_d = p.mir.l0_d + (size_t)target * 2u * p.mir.m; gl_cnt16 = p.mir.l0_cnt + target; }
+        else { const uint32_t blk = p.mir.up_block[target] + layer - 1; gl_ids = p.mir.up_ids + (size_t)blk * p.mir.m; gl_d = p.mir.up_d + (size_t)blk * p.mir.m; gl_cnt16 = p.mir.up_cnt + blk; }
+        cnt = *gl_cnt16;
+    } else { gl_ids = p.ids + (size_t)g * p.lm0; gl_d = p.d + (size_t)g * p.lm0; lm = p.lm[g]; cnt = p.cnt[g]; }
+    for (uint32_t i = lane; i < cnt; i += 64) { LID[i] = gl_ids[i]; LD[i] = gl_d[i]; HND[i] = i; }
     const float qnan = __builtin_nanf("");
     for (uint32_t i = lane; i < (lm + 1u) * lm / 2u; i += 64) M[i] = qnan;
     uint32_t hfree = lm;                                                            // the handle no list position holds once the list is full
     F_WSYNC();
     unsigned long long ndist = 0;
     constexpr uint32_t B = OP::kSparse ? 64u : f_step_rows<LPR>();               // sparsevec: one lane per row, so a step holds a lane-full of rows
-    for (uint32_t op = p.op_off[g]; op < p.op_off[g + 1]; op++) {
+    const uint32_t *op_off = mirror ? p.mir.op_off : p.op_off, *op_new = mirror ? p.mir.op_new : p.op_new; const float *op_d = mirror ? p.mir.op_d : p.op_d;
+    for (uint32_t op = op_off[g]; op < op_off[g + 1]; op++) {
         if (cnt < lm) {                                                             // mod.rs:469-471
-            if (lane == 0) { LID[cnt] = p.op_new[op]; LD[cnt] = p.op_d[op]; HND[cnt] = cnt; }
+            if (lane == 0) { LID[cnt] = op_new[op]; LD[cnt] = op_d[op]; HND[cnt] = cnt; }
             cnt++; F_WSYNC();
             continue;
         }
         const uint32_t n = cnt + 1;                                                 // mod.rs:474-482: the list + the new element, stable sort by distance
-        if (lane == 0) { LID[cnt] = p.op_new[op]; LD[cnt] = p.op_d[op]; HND[cnt] = hfree; }
+        if (lane == 0) { LID[cnt] = op_new[op]; LD[cnt] = op_d[op]; HND[cnt] = hfree; }
         for (uint32_t j = lane; j <= lm; j += 64) if (j != hfree) M[bl_tri(hfree, j)] = qnan;   // the handle's previous owner is gone
         F_WSYNC();
         for (uint32_t i = lane; i < n; i += 64) {
@@ -167,8 +178,13 @@ k_list_ops(const ListOpsParams p)
         cnt = nR;
         F_WSYNC();
     }
-    for (uint32_t i = lane; i < cnt; i += 64) { p.ids[(size_t)g * p.lm0 + i] = LID[i]; p.d[(size_t)g * p.lm0 + i] = LD[i]; }
-    if (lane == 0) { p.cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
+    for (uint32_t i = lane; i < cnt; i += 64) { gl_ids[i] = LID[i]; gl_d[i] = LD[i]; }
+    if (mirror && p.mir.xrec) {                                                     // multi-GPU builds: the updated list as a self-describing record
+        uint32_t *xr = p.mir.xrec + (size_t)g * p.mir.xrec_words;
+        for (uint32_t i = lane; i < cnt; i += 64) { xr[3 + i] = LID[i]; xr[3 + 2u * p.mir.m + i] = __builtin_bit_cast(unsigned int, LD[i]); }
+        if (lane == 0) { xr[0] = target; xr[1] = layer; xr[2] = cnt; }
+    }
+    if (lane == 0) { if (mirror) *gl_cnt16 = (uint16_t)cnt; else p.cnt[g] = cnt; atomicAdd(p.n_pairs, ndist); }
 }
 
 // k_update_runs (hx_links.hip) for lists of more than 64 slots: every back-connection a batch of aminserts makes to one list, applied in order --
@@ -376,6 +392,7 @@ int hx_engine::biglist_ops_run(uint64_t *n_pairs, bool disk)
     p.ids = (uint32_t *)(mr.d_lk + bl_o_ids); p.d = (float *)(mr.d_lk + bl_o_d); p.cnt = (uint32_t *)(mr.d_lk + bl_o_cnt);
     p.lm = (const uint32_t *)(mr.d_lk + bl_o_lm); p.op_off = (const uint32_t *)(mr.d_lk + bl_o_off); p.op_new = (const uint32_t *)(mr.d_lk + bl_o_new);
     p.op_d = (const float *)(mr.d_lk + bl_o_od); p.n_pairs = (unsigned long long *)mr.d_lk;
+    p.mir = ListMirrorArgs{};
     if (timing) HX_HIP(this, hipEventRecord(ev2, stream));
     hipError_t ls = hipSuccess;
 #define F32C(K) ls = launch_list_ops<OpF32<K>>(this, p, disk)
@@ -394,4 +411,20 @@ int hx_engine::biglist_ops_run(uint64_t *n_pairs, bool disk)
     if (timing) { float ms = 0.f; HX_HIP(this, hipEventElapsedTime(&ms, ev2, ev3)); last_ms = ms; stat_links.launches++; stat_links.units += np; stat_links.ms += ms; }
     bl_groups = 0;
     return HX_OK;
+}
+
+// the batch pipeline's ordinary groups of lists with 33..64 slots (m = 17..32), in place on the device mirror: the lazily filled pair memo instead of
+// k_links_cached's eagerly completed pair matrix (2 016 pairs per touched list and batch when there is no resident matrix to start from)
+hipError_t hx_launch_list_ops_mirror(hx_engine *e, const ListMirrorArgs &a)
+{
+    ListOpsParams p{};
+    p.rows = e->d_rows; p.pitch = (uint32_t)e->pitch; p.cap = 0u; p.n_groups = a.n_groups; p.lm0 = 2u * a.m;
+    p.n_pairs = a.n_pairs; p.mir = a;
+    hipError_t ls = hipSuccess;
+#define F32C(K) ls = launch_list_ops<OpF32<K>>(e, p, false)
+#define F16C(K) ls = launch_list_ops<OpF16<K>>(e, p, false)
+    HX_DISPATCH(e, F32C, F16C, ls = launch_list_ops<OpHamming>(e, p, false), ls = launch_list_ops<OpJaccard>(e, p, false));
+#undef F32C
+#undef F16C
+    return ls;
 }

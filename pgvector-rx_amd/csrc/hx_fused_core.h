@@ -84,6 +84,13 @@ __device__ __forceinline__ KParams &f_params_here(KParams &p) { KParams *q = &p;
 hipError_t hx_launch_fused_f32(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_f16(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
 hipError_t hx_launch_fused_bit(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);
+// hx_biglist.hip: k_list_ops working on the device mirror's lists (the batch pipeline's groups of lists of 33..64 slots, m = 17..32)
+struct ListMirrorArgs {
+    uint32_t n_groups, m; const uint32_t *target, *layer, *op_off, *op_new, *gmap; const float *op_d;
+    uint32_t *l0_ids; float *l0_d; uint16_t *l0_cnt; const uint32_t *up_block; uint32_t *up_ids; float *up_d; uint16_t *up_cnt;
+    uint32_t *xrec; uint32_t xrec_words; unsigned long long *n_pairs;
+};
+hipError_t hx_launch_list_ops_mirror(hx_engine *e, const ListMirrorArgs &a);
 hipError_t hx_launch_fused_sparse(hx_engine *e, int metric, const FusedParams &p, uint32_t grid, size_t lds, int mode);   // modes 0, 2, 3 (scans and search-only inserts)
 
 // what the query-vs-rows helpers below need: the row store and 64 floats of LDS scratch for the short-row path.  Kept apart from FusedParams

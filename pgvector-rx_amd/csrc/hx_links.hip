@@ -1150,6 +1150,15 @@ int hx_engine::links_run_grouped(uint32_t n_ops, const unsigned long long *keys,
 #undef F32C
 #undef F16C
     }
+    static const bool memo_lists = !(getenv("HX_LINKS_MEMO") && atoi(getenv("HX_LINKS_MEMO")) == 0);
+    if (ls == hipSuccess && n_norm && !use_pm && 2 * mr.m > 32 && memo_lists) {
+        // lists of 33..64 slots have no resident pair matrix: k_list_ops' lazily filled memo (hx_biglist.hip) instead of completing 2 016 pairs per touched list
+        ListMirrorArgs a{};
+        a.n_groups = n_norm; a.m = mr.m; a.target = grp.tg; a.layer = grp.ly; a.op_off = grp.off; a.op_new = grp.op_new; a.gmap = grp.gmap_norm; a.op_d = grp.op_d;
+        a.l0_ids = mr.d_l0_ids; a.l0_d = mr.d_l0_d; a.l0_cnt = mr.d_l0_cnt; a.up_block = mr.d_up_block; a.up_ids = mr.d_up_ids; a.up_d = mr.d_up_d; a.up_cnt = mr.d_up_cnt;
+        a.xrec = p.xrec; a.xrec_words = p.xrec_words; a.n_pairs = p.n_pairs;
+        ls = hx_launch_list_ops_mirror(this, a);
+    } else
     if (ls == hipSuccess && n_norm) {
         p.n_groups = n_norm; p.gmap = grp.gmap_norm;
 #define F32C(K) ls = launch_links_cached<OpF32<K>>(this, p)

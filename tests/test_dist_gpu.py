@@ -52,6 +52,17 @@ def test_multi_process_build_equals_single_process(world, fmt, shape):
     assert all(int(o[4]) == 0 for o in outs)
 
 
+def test_multi_process_build_with_lists_of_33_to_64_slots():
+    """m = 20 (lists of 40): the device batch pipeline prunes these lists with k_list_ops' pair memo on the mirror (hx_biglist.hip) and hands the pruned lists
+    to the other ranks as device records -- same graph as one process builds."""
+    shape = (2500, 32, 20, 48, 400, hx.F32, hx.L2SQ)
+    single = run_world(1, list(shape) + [1])[0]
+    outs = run_world(2, list(shape) + [1])
+    assert all(int(o[1]) == shape[0] for o in outs)
+    assert all(o[0] == single[0] and o[2] == single[2] for o in outs), (single, outs)
+    assert all(int(o[3]) > 0 and int(o[4]) == 0 for o in outs)
+
+
 def test_multi_process_build_with_lists_of_more_than_64_slots():
     """m = 40: the device batch pipeline does not serve the shape, so the ranks exchange serialized lists (hx_index_batch_*); searches, select_neighbors and
     the owned lists' back-links still run in device kernels on every rank (hx_biglist.hip) -- same graph as one process builds."""
