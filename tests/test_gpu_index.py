@@ -763,7 +763,8 @@ def test_scans_run_in_the_traversal_kernel_for_every_legal_m(dtype, metric, dim,
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,metric,dim,m,efc,batch", [
     (hx.F32, hx.L2SQ, 6, 40, 80, 64), (hx.F32, hx.NEG_IP, 24, 64, 128, 200), (hx.F16, hx.L2SQ, 40, 100, 200, 97),
-    (hx.BIT, hx.HAMMING, 64, 100, 200, 64), (hx.F32, hx.L1, 300, 50, 120, 128), (hx.F16, hx.NEG_IP, 600, 33, 70, 1)])
+    (hx.BIT, hx.HAMMING, 64, 100, 200, 64), (hx.F32, hx.L1, 300, 50, 120, 128), (hx.F16, hx.NEG_IP, 600, 33, 70, 1),
+    (hx.F32, hx.L2SQ, 8, 40, 500, 128)])                                            # result sets of up to 500 candidates through k_select_w
 def test_builds_for_every_legal_m_stay_on_the_device(dtype, metric, dim, m, efc, batch):
     """m in 33..100 (options.rs:203-225): the searches run in k_fused (MODE 3), select_neighbors in k_select_w and update_neighbor_connections in
     k_list_ops (hx_biglist.hip: lists of up to 200 slots walked 64 at a time, pair distances evaluated as check_element_closer asks for them).
