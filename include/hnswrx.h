@@ -238,7 +238,7 @@ int hx_index_dbatch_end(hx_index *ix, uint32_t *elem_out);
  * batch > 1: the neighbour searches of `batch` rows run against the same graph, as concurrent backends would.
  * Placement: searches in the traversal kernel (MODE 3), back-connections in k_update_runs (one wavefront per list) while no deleted / TID-less
  * element can be met, else k_update_index in waves; hx_index_set_fused(0): everything on the lock-step driver.  Every legal m; m > 32 needs
- * the device placement (dense rows <= 8 KiB) and an index whose deleted elements are unlinked (HX_E_ARG / HX_E_STATE otherwise). */
+ * the device placement (rows <= 8 KiB) and an index whose deleted elements are unlinked (HX_E_ARG / HX_E_STATE otherwise). */
 int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const int32_t *levels, const int64_t *tids,
                            uint32_t batch, uint32_t *elem_out);
 /* ambulkdelete + amvacuumcleanup (src/index/vacuum.rs): dead_tids = the heap TIDs the bulk-delete callback reports dead.  Pass 1

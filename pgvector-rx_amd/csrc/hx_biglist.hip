@@ -268,7 +268,7 @@ static hipError_t launch_list_ops(hx_engine *e, const ListOpsParams &p, bool dis
     const size_t nch = (e->pitch + 1023) / 1024;
     const size_t lds = (8 * BL_MAX + 64) * 4 + nch * 1024;
     if (disk) {
-        if constexpr (OP::kSparse) return hipErrorInvalidValue;                       // aminsert's back-connections on sparsevec rows: lock-step driver
+        if constexpr (OP::kSparse) hipLaunchKernelGGL((k_update_runs_big<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
         else if (e->pitch <= 128) hipLaunchKernelGGL((k_update_runs_big<OP, 8>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
         else if (e->pitch <= 512) hipLaunchKernelGGL((k_update_runs_big<OP, 32>), dim3(p.n_groups), dim3(64), lds, e->stream, p);
         else hipLaunchKernelGGL((k_update_runs_big<OP, 64>), dim3(p.n_groups), dim3(64), lds, e->stream, p);

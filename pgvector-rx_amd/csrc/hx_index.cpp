@@ -1940,8 +1940,8 @@ int hx_index_insert_ondisk(hx_index *ix, uint64_t first_row, uint32_t n, const i
     if (first_row != g.size()) return ix->fail(HX_E_STATE, "rows must be inserted in append order: first_row != index size");
     if (first_row + n > hx_num_rows(ix->e)) return ix->fail(HX_E_ARG, "rows not present in the engine");
     const bool big = 2 * g.m > (int)HX_PAIR_MAX_ROWS;                               // lists of more than 64 slots: device kernels only (hx_biglist.hip)
-    if (big && !(ix->fused && ix->e->dtype != HX_SPARSE && ix->e->pitch <= 8192))
-        return ix->fail(HX_E_ARG, "m > 32: the on-disk insert path runs in the device kernels only (dense rows <= 8 KiB, hx_index_set_fused(1))");   // (k_update_runs_big: dense operators)
+    if (big && !(ix->fused && ix->e->pitch <= 8192))
+        return ix->fail(HX_E_ARG, "m > 32: the on-disk insert path runs in the device kernels only (rows <= 8 KiB, hx_index_set_fused(1))");
     if (batch == 0) batch = 1;
     hx_index::Timer t_all(ix->prof[10]);
     int rc = ix->ensure_host_lists();

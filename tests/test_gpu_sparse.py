@@ -171,3 +171,49 @@ def test_sparse_create_limits():
     e = hx.Engine(hx.SPARSE, hx.L2SQ, 1000000000, 4)
     assert e.row_bytes == 16 + 8 * 1000
     e.close()
+
+
+@pytest.mark.gpu
+def test_sparse_aminsert_and_vacuum_with_lists_of_more_than_64_slots():
+    """sparsevec at m = 40 through aminsert (k_fused<OpSparse> MODE 3 + k_update_runs_big<OpSparse>), a VACUUM and more inserts: the oracle's graph after each step."""
+    rng = np.random.default_rng(40)
+    dim, n, m, efc = 300, 260, 40, 80
+    rows = random_sparse(rng, n, dim, 20)
+    rec = hx.pack_sparse(dim, rows)
+    levels = hx.draw_levels(n, m, seed=4)
+    e = hx.Engine(hx.SPARSE, hx.L2SQ, dim, n)
+    e.append(rec)
+    ix = hx.Index(e, m, efc)
+    o = orc.Index(orc.SPARSE, orc.L2SQ, dim, m=m, ef_construction=efc)
+    o.set_ondisk_tombstones(True)
+    tids = np.arange(1, n + 1, dtype=np.int64)
+
+    def same(size):
+        assert ix.size == o.size == size and ix.entry == o.entry
+        for i in range(size):
+            if o.merged(i):
+                assert ix.level(i) < 0
+                continue
+            assert ix.deleted(i) == o.deleted(i)
+            for layer in range(ix.level(i) + 1):
+                gi, gd = ix.neighbors(i, layer)
+                oi, od = o.neighbors(i, layer)
+                assert gi.tolist() == oi.tolist(), (i, layer)
+                assert (gd.view(np.uint32) == od.view(np.uint32)).all(), (i, layer)
+
+    ix.insert_ondisk(0, levels[:200], tids=tids[:200], batch=1)
+    for i in range(200):
+        o.insert_on_disk(rec[i], int(levels[i]), int(tids[i]))
+    same(200)
+    assert max(len(ix.neighbors(i, 0)[0]) for i in range(200)) == 2 * m
+    kill = tids[:200][::4].copy()
+    ix.vacuum(kill, batch=1)
+    o.vacuum(kill)
+    same(200)
+    ix.insert_ondisk(200, levels[200:], tids=tids[200:], batch=1)
+    for i in range(200, n):
+        o.insert_on_disk(rec[i], int(levels[i]), int(tids[i]))
+    same(n)
+    assert ix.profile()["rounds"] <= 2 * n                                          # one kernel per insert for the back-connections, no lock-step expansion rounds
+    ix.close()
+    e.close()
