@@ -547,6 +547,7 @@ struct QueryTask : LsTask {
             switch (st) {
             case Q_INIT:
                 if (g->entry < 0) { st = Q_DONE; break; }                            // scan.rs:469-472
+                sc.deleted = g->deleted.data();                                      // load_element -> None for a deleted tuple (scan.rs:178-181): visited, not a candidate
                 dist_ids.push_back((uint32_t)g->entry); q_sel = HX_QUERY_SLOT | slot; n_dist += 1; st = Q_ENTRY;
                 return true;
             case Q_ENTRY:
@@ -829,6 +830,9 @@ struct hx_index {
     // scans: the traversal kernel walks lists longer than a wavefront 64 ids at a time, so every m the reference allows (options.rs:203-225: m <= 100) is served;
     // only the insert-mode kernel and the back-link kernels are built for lists of <= 64
     bool fused_scan_ok() const { return fused && e->pitch <= 8192; }   // round 3: sparsevec too (hx_fused_sparse.hip: one lane per row walks the merge join)
+    // scans: the kernels do not model load_element -> None for a deleted element (scan.rs:178-181: skipped, not counted), so while one can be met
+    // (dead_refs: only the un-repairable entry point of vacuum.rs:300-303) scans stay on the lock-step driver, which does
+    bool device_scan_ok() const { return fused_scan_ok() && !dead_refs; }
     // device-resident batches (hx_batch.hip): the traversal kernel and the back-link kernels both serve this m
     bool dbatch_ok() const { static const bool off = getenv("HX_DEVICE_BATCH") && atoi(getenv("HX_DEVICE_BATCH")) == 0; return !off && fused_ok() && 2 * g.m <= 64; }
     void mark_dirty(uint32_t elem) { for (int lc = 0; lc <= g.level[elem]; lc++) dirty.emplace_back(elem, lc); }
@@ -2610,7 +2614,7 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
     if (ef_search < 1 || ef_search > 1000) return ix->fail(HX_E_ARG, "hnsw.ef_search must be between 1 and 1000");   // options.rs:156-166
     if (nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
     std::vector<uint32_t> todo;                                  // query slots for the lock-step path
-    if (mode == 0 && ix->fused_scan_ok() && ix->g.entry >= 0) {
+    if (mode == 0 && ix->device_scan_ok() && ix->g.entry >= 0) {
         const double t_sm0 = hx_index::now_s();
         int rc = ix->sync_mirror();
         if (rc) return rc;
@@ -2629,7 +2633,7 @@ static int search_impl(hx_index *ix, uint32_t nq, uint32_t ef_search, int mode, 
         if ((rc = finish_device_scan(ix, v, 0, nq, ef_search, limit, tids_out, dist_out, elems_out, counts_out, todo))) return rc;
         ix->fused_tasks += nq; ix->fused_redo += todo.size();
         if (todo.empty()) return HX_OK;
-    } else if (mode != 0 && ix->fused_scan_ok() && ix->g.entry >= 0 && limit <= 4096) {
+    } else if (mode != 0 && ix->device_scan_ok() && ix->g.entry >= 0 && limit <= 4096) {
         // iterative scan on the device (k_fused MODE 2): the filter reaches the kernel as a per-element mask of passing heap TIDs
         int rc = ix->sync_mirror();
         if (rc) return rc;
@@ -2700,7 +2704,7 @@ int hx_index_search_submit(hx_index *ix, uint32_t slot, uint32_t first_query, ui
     if ((uint64_t)first_query + nq > ix->e->n_queries) return ix->fail(HX_E_STATE, "upload the queries with hx_set_queries first");
     hx_index::ScanSlot &ss = ix->scan_slot[slot];
     if (ss.busy) return ix->fail(HX_E_STATE, "scan slot busy: hx_index_search_wait first");
-    if (!ix->fused_scan_ok() || ix->g.entry < 0) return ix->fail(HX_E_STATE, "this index does not scan on the device (empty, sparsevec or hx_index_set_fused(0)): use hx_index_search");
+    if (!ix->device_scan_ok() || ix->g.entry < 0) return ix->fail(HX_E_STATE, "this index does not scan on the device (empty, hx_index_set_fused(0), or a deleted element can still be met): use hx_index_search");
     int rc;
     if (ix->scans_in_flight == 0) { if ((rc = ix->sync_mirror())) return rc; }
     else if (ix->g.size() != ix->mirror_elems || !ix->dirty.empty()) return ix->fail(HX_E_STATE, "the index was modified while a scan is in flight");

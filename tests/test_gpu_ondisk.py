@@ -345,11 +345,20 @@ def test_unrepairable_entry_point_keeps_the_lock_step_driver():
     assert_same_graph(ix, o, n0)
     assert any(ix.deleted(int(j)) for j in ix.neighbors(keep, 0)[0])          # the survivor still names deleted elements
     before = ix.fused_stats()["tasks"]
+    qs = make_rows(hx.F32, 6, dim, rng)
+    e.set_queries(qs)
+    t, d, _, cnt = ix.search(6, 10, 5)                                         # scans meet load_element -> None too: lock-step driver, the oracle's answer
+    for q in range(6):
+        assert t[q, :cnt[q]].tolist() == [x for x, _, _ in o.scan(qs[q], ef_search=10, limit=5)]
+    assert ix.fused_stats()["tasks"] == before
     ix.insert_ondisk(n0, levels[n0:], tids=tids[n0:], batch=1)
     assert ix.fused_stats()["tasks"] == before                                 # no device search while deleted elements can be met
     for i in range(n0, n0 + extra):
         o.insert_on_disk(rows[i], int(levels[i]), int(tids[i]))
     assert_same_graph(ix, o, n0 + extra)
+    t, d, _, cnt = ix.search(6, 20, 8)
+    for q in range(6):
+        assert t[q, :cnt[q]].tolist() == [x for x, _, _ in o.scan(qs[q], ef_search=20, limit=8)]
     ix.close()
     e.close()
 
