@@ -400,3 +400,86 @@ def test_ondisk_batches_device_search_equals_lock_step_search(dtype, metric, dim
         valid = np.arange(ia.shape[1])[None, :] < ca[:, None]
         assert np.array_equal(np.where(valid, ia, 0), np.where(valid, ib, 0))
         assert np.array_equal(np.where(valid, da.view(np.uint32), 0), np.where(valid, dbb.view(np.uint32), 0))
+
+
+@pytest.mark.parametrize("mods", [(97, 350, 911), (3, 5, 7)], ids=["mostly-distinct", "105-distinct-rows"])
+def test_reference_011_delete_all_vacuum_reinsert_then_all_but_one(mods):
+    """tests/t/011_hnsw_vacuum.pl on the engine: CREATE INDEX over 10 000 rows ARRAY[i % a, i % b, i % c], DELETE all + VACUUM, the same rows through aminsert,
+    DELETE all but i = 123 + VACUUM, then `ORDER BY v <-> '[0,0,0]' LIMIT 10` returns 123 alone (:45-52; the size assertion :40-42 is the storage manager's).
+    Small moduli make most rows duplicates of one another (heap-TID lists of 10, then new elements).  Graph, deleted flags and answers equal the oracle's at every step."""
+    n, dim, m, efc = 10_000, 3, 16, 64
+    i = np.arange(1, n + 1)
+    rows = np.stack([i % mods[0], i % mods[1], i % mods[2]], axis=1).astype(np.float32)
+    all_rows = np.concatenate([rows, rows])
+    levels = hx.draw_levels(2 * n, m, seed=11)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, 2 * n)
+    e.append(all_rows)
+    ix = hx.Index(e, m, efc)
+    o = orc.Index(orc.F32, orc.L2SQ, dim, m=m, ef_construction=efc, order=orc.W64)
+    o.set_ondisk_tombstones(True)
+    tids = np.arange(1, n + 1, dtype=np.int64)
+    ix.insert(0, levels[:n], tids=tids, batch=512)
+    at = 0
+    for b in hx.batch_schedule(0, n, 512):
+        o.insert_batch(rows[at:at + b], levels[at:at + b], tids[at:at + b])
+        at += b
+    assert_same_graph(ix, o, n)
+    ix.vacuum(tids, batch=1)                                                       # DELETE FROM tst; VACUUM tst;
+    o.vacuum(tids)
+    assert ix.entry == o.entry and all(ix.deleted(k) == o.deleted(k) for k in range(n))
+    tids2 = np.arange(n + 1, 2 * n + 1, dtype=np.int64)                            # new heap tuples
+    ix.insert_ondisk(n, levels[n:], tids=tids2, batch=1)
+    for k in range(n):
+        o.insert_on_disk(rows[k], int(levels[n + k]), int(tids2[k]))
+    assert_same_graph(ix, o, 2 * n)
+    q0 = np.zeros((1, dim), np.float32)
+    e.set_queries(q0)
+    t, d, _, cnt = ix.search(1, 40, 10)
+    assert t[0, :cnt[0]].tolist() == [x for x, _, _ in o.scan(q0[0], ef_search=40, limit=10)] and cnt[0] == 10
+    keep = int(tids2[122])                                                         # i = 123
+    kill = tids2[tids2 != keep]
+    ix.vacuum(kill, batch=1)                                                       # DELETE FROM tst WHERE i != 123; VACUUM tst;
+    o.vacuum(kill)
+    assert all(ix.deleted(k) == o.deleted(k) for k in range(2 * n))
+    t, d, _, cnt = ix.search(1, 40, 10)
+    assert t[0, :cnt[0]].tolist() == [keep] == [x for x, _, _ in o.scan(q0[0], ef_search=40, limit=10)]   # is($res, 123)
+    ix.close()
+    e.close()
+
+
+def test_reference_016_concurrent_inserts_into_an_empty_index():
+    """tests/t/016_hnsw_inserts.pl on the engine (vector(1900): 7 600-byte rows): 20 times, 10 concurrent single-row INSERTs into an EMPTY index
+    (pgbench --client=10 --transactions=1 = one aminsert batch of 10), then an index scan from one of the rows must return all 10 (:43-47); and 1 000 rows
+    from 20 concurrent clients inserting 10 rows per statement, 5 transactions each, after which a scan at ef_search 1000 returns >= 997 rows (:63-70)."""
+    rng = np.random.default_rng(16)
+    dim, m, efc = 1900, 16, 64
+    for trial in range(20):
+        rows = rng.random((10, dim), dtype=np.float32)
+        e = hx.Engine(hx.F32, hx.L2SQ, dim, 10)
+        e.append(rows)
+        ix = hx.Index(e, m, efc)
+        levels = hx.draw_levels(10, m, seed=100 + trial)
+        ix.insert_ondisk(0, levels, tids=np.arange(1, 11, dtype=np.int64), batch=10)
+        e.set_queries(rows[:1])
+        t, d, _, cnt = ix.search(1, 40, 1000)
+        assert cnt[0] == 10 and sorted(t[0, :10].tolist()) == list(range(1, 11)), trial        # is($count, 10)
+        ix.close()
+        e.close()
+    n = 1000
+    rows = rng.random((n, dim), dtype=np.float32)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    levels = hx.draw_levels(n, m, seed=16)
+    tids = np.arange(1, n + 1, dtype=np.int64)
+    at = 0
+    for _ in range(5):                                                             # 5 transactions: each one 20 clients x 10 rows, every client's statement inserting its rows one after the other
+        for k in range(10):
+            ix.insert_ondisk(at, levels[at:at + 20], tids=tids[at:at + 20], batch=20)
+            at += 20
+    e.set_queries(rows[:1])
+    t, d, _, cnt = ix.search(1, 1000, 1000)
+    assert cnt[0] >= 997, cnt[0]                                                   # cmp_ok($count, ">=", 997)
+    assert len(set(t[0, :cnt[0]].tolist())) == cnt[0]
+    ix.close()
+    e.close()
