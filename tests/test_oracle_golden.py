@@ -596,3 +596,29 @@ def test_sparsevec_vacuum_insert_rounds():
             if not idx.deleted(e) and not idx.merged(e):
                 for layer in range(idx.level(e) + 1):
                     assert all(not idx.deleted(int(x)) for x in idx.neighbors(e, layer)[0])
+
+
+@pytest.mark.parametrize("mods", [(97, 350, 911), (3, 5, 7)], ids=["mostly-distinct", "105-distinct-rows"])
+def test_reference_011_all_but_one_comes_back(mods):
+    """tests/t/011_hnsw_vacuum.pl:29-52 on the oracle: build over 10 000 rows ARRAY[i % a, i % b, i % c], delete all + vacuum, the same rows through aminsert,
+    delete all but i = 123 + vacuum: `ORDER BY v <-> '[0,0,0]' LIMIT 10` returns 123 alone (the survivor is the entry point, which vacuum.rs:300-303 does not
+    repair against itself: its lists still name deleted tuples, and load_element skips those, scan.rs:178-181)."""
+    n, dim, m, efc = 10_000, 3, 16, 64
+    i = np.arange(1, n + 1)
+    rows = np.stack([i % mods[0], i % mods[1], i % mods[2]], axis=1).astype(np.float32)
+    levels = orc.levels_from_seed(2 * n, m, 11).astype(np.int32)
+    o = orc.Index(orc.F32, orc.L2SQ, dim, m=m, ef_construction=efc)
+    o.set_ondisk_tombstones(True)
+    tids = np.arange(1, n + 1, dtype=np.int64)
+    for k in range(n):
+        o.insert_batch(rows[k:k + 1], levels[k:k + 1], tids[k:k + 1])
+    o.vacuum(tids)
+    assert o.entry < 0
+    tids2 = np.arange(n + 1, 2 * n + 1, dtype=np.int64)
+    for k in range(n):
+        o.insert_on_disk(rows[k], int(levels[n + k]), int(tids2[k]))
+    q0 = np.zeros(dim, np.float32)
+    assert len(o.scan(q0, ef_search=40, limit=10)) == 10
+    keep = int(tids2[122])
+    o.vacuum(tids2[tids2 != keep])
+    assert [t for t, _, _ in o.scan(q0, ef_search=40, limit=10)] == [keep]
