@@ -222,6 +222,39 @@ def test_regress_orderings_on_device(case):
     e.close()
 
 
+@pytest.mark.parametrize("case", G["in_source_spi_tests"]["cases"], ids=lambda c: c["ref"].split("/")[-1])
+def test_in_source_spi_cases_on_device(case):
+    """The #[pg_test] cases of the reference's scan.rs / insert.rs / vacuum.rs that pin results of the path, through the C ABI: rows through hx_index_insert
+    (build_callback), more rows through hx_index_insert_ondisk (aminsert), one scan."""
+    dim, cosine = case["dim"], case["opclass"] == "cosine"
+    n = len(case["build"]) + len(case["insert"])
+    e = hx.Engine(hx.F32, METRIC[case["opclass"]], dim, max(n, 1))
+    ix = hx.Index(e, 16, 64)
+    rows = []
+    for phase, src in (("build", case["build"]), ("insert", case["insert"])):
+        for r in src:
+            first = e.append(np.asarray(r, np.float32)[None, :])
+            if cosine:
+                assert e.normalize_rows(first, 1)[0] != 0.0
+            if phase == "build":
+                ix.insert(first, [0], tids=[len(rows)], batch=1)
+            else:
+                ix.insert_ondisk(first, [0], tids=[len(rows)], batch=1)
+            rows.append(r)
+    e.set_queries(np.asarray(case["query"], np.float32)[None, :], normalize=cosine)
+    limit = case["limit"] if case["limit"] is not None else 1000
+    if case.get("iterative"):
+        tids, _, cnt = ix.search_iterative(1, case.get("ef_search", 40), 2 if case["iterative"] == "strict_order" else 1, 20000, limit)
+    else:
+        tids, _, _, cnt = ix.search(1, case.get("ef_search", 40), limit)
+    if "expect_first" in case:
+        assert [float(x) for x in rows[tids[0, 0]]] == [float(x) for x in case["expect_first"]]
+    if "expect_count" in case:
+        assert cnt[0] == case["expect_count"]
+    ix.close()
+    e.close()
+
+
 @pytest.mark.parametrize("case", G["null_query_count"], ids=lambda c: c["ref"].split("/")[-1])
 def test_null_and_zero_query_counts_on_device(case):
     """`ORDER BY val <-> (SELECT NULL::vector)` and the zero-vector cosine query of the reference's pg_regress files (scan.rs:186-187) on an index the

@@ -622,3 +622,32 @@ def test_reference_011_all_but_one_comes_back(mods):
     keep = int(tids2[122])
     o.vacuum(tids2[tids2 != keep])
     assert [t for t, _, _ in o.scan(q0, ef_search=40, limit=10)] == [keep]
+
+
+@pytest.mark.parametrize("case", G["in_source_spi_tests"]["cases"], ids=lambda c: c["ref"].split("/")[-1])
+def test_in_source_spi_cases(case):
+    """The #[pg_test] cases of the reference's scan.rs / insert.rs / vacuum.rs that pin results of the path: rows through build_callback, more rows through
+    aminsert, one ORDER BY scan."""
+    dim, cosine = case["dim"], case["opclass"] == "cosine"
+    idx = orc.Index(orc.F32, METRIC[case["opclass"]], dim, m=16, ef_construction=64)
+    idx.set_ondisk_tombstones(True)
+    rows = []
+    for phase, src in (("build", case["build"]), ("insert", case["insert"])):
+        for r in src:
+            v = np.asarray(r, np.float32)
+            if cosine:
+                v, norm = orc.l2_normalize(orc.F32, dim, v)
+                assert norm != 0.0
+            if phase == "build":
+                idx.insert(v, 0, len(rows))
+            else:
+                idx.insert_on_disk(v, 0, len(rows))
+            rows.append(r)
+    q = np.asarray(case["query"], np.float32)
+    if cosine:
+        q, _ = orc.l2_normalize(orc.F32, dim, q)
+    res = idx.scan(q, ef_search=case.get("ef_search", 40), iterative=ITER[case.get("iterative")], limit=case["limit"])
+    if "expect_first" in case:
+        assert [float(x) for x in rows[res[0][0]]] == [float(x) for x in case["expect_first"]]
+    if "expect_count" in case:
+        assert len(res) == case["expect_count"]
