@@ -283,7 +283,7 @@ int hx_index_mfma_stats(const hx_index *ix, uint64_t *mfma_pairs, uint64_t *exac
 int hx_index_fused_stats(const hx_index *ix, uint64_t *tasks, uint64_t *redone);
 
 /* host-side wall time of the lock-step driver since the last reset, seconds: [0] task state machines,
- * [1] request compaction, [2] request fill, [3] round copies+launches+wait, [4] unused, [5] rounds, [6] fused kernel calls, [7] mirror sync, [8] link-stage setup, [9] link-stage lock-step, [10] hx_index_insert total,
+ * [1] request compaction, [2] request fill, [3] round copies+launches+wait (also the aminsert update kernels), [4] mirror sync of plain scans, [5] rounds (lock-step rounds + aminsert update-kernel launches), [6] fused kernel calls, [7] mirror sync, [8] link-stage setup (aminsert: the member stage), [9] link-stage kernels / lock-step (aminsert: the update stage), [10] hx_index_insert / hx_index_insert_ondisk total,
  * [11] batch_search total, [12] batch_begin total */
 int hx_index_profile(const hx_index *ix, double seconds_out[16], int reset);
 
