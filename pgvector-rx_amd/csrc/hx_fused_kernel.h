@@ -711,7 +711,7 @@ __device__ __forceinline__ void f_worker(KParams &p_in, uint8_t *lds, const uint
 }
 
 template <class OP, int MODE, int LPR, bool SA = false>
-__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : (MODE == 1 || MODE == 3) ? FUSED_MINW_INS : SA ? FUSED_MINW_SA : FUSED_MINW))
+__global__ void __launch_bounds__(64, (MODE == 2 ? FUSED_MINW_ITER : (MODE == 1 || MODE == 3) ? FUSED_MINW_INS : SA ? FUSED_MINW_SA : OP::query_minw ? OP::query_minw : FUSED_MINW))
 k_fused(const FusedParams p_unused)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];

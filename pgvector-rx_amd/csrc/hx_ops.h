@@ -83,6 +83,7 @@ template <int KIND> __device__ __forceinline__ void fterm(float &acc, float x, f
 
 template <int KIND> struct OpF32 {
     static constexpr bool kSparse = false;
+    static constexpr int query_minw = 0;              // k_fused<query>: waves per SIMD the register budget is cut for (0: FUSED_MINW)
     static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = true;    // real-valued distances: ties are rare enough for k_fused's sorted-array searches
     typedef float acc_t;
@@ -103,6 +104,7 @@ template <int KIND> struct OpF32 {
 
 template <int KIND> struct OpF16 {
     static constexpr bool kSparse = false;
+    static constexpr int query_minw = KIND == K_L1 ? 0 : 3;   // the f16 -> f32 widening of L2 / inner product needs 141 VGPRs: at 4 waves per SIMD (128) the query kernel spilled 25 of them (56 B scratch); 3 waves, no spills (C4 shape +3.5 % queries/s)
     static constexpr bool mfma_split_ok = KIND == K_IP;   // k_fused MODE 3: select_neighbors on the matrix cores (halfvec inner product is a true f16 GEMM)
     static constexpr bool sorted_array_ok = true;
     typedef float acc_t;
@@ -126,6 +128,7 @@ template <int KIND> struct OpF16 {
 
 struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
     static constexpr bool kSparse = false;
+    static constexpr int query_minw = 0;
     static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = false;   // integer-valued: ties everywhere, the heap kernels only
     typedef int acc_t;
@@ -143,6 +146,7 @@ struct OpHamming {   // bitvec.rs:97-106: popcount(a ^ b); integer, order-free
 struct JacAcc { int ab, aa, bb; };
 struct OpJaccard {   // bitvec.rs:113-132
     static constexpr bool kSparse = false;
+    static constexpr int query_minw = 0;
     static constexpr bool mfma_split_ok = false;
     static constexpr bool sorted_array_ok = false;
     typedef JacAcc acc_t;
@@ -254,6 +258,7 @@ __device__ float sp_merge(const SpRow a, const SpRow b)
 // the traversal kernel's view of the type: no chunk-wise accumulation -- f_dist_batch hands a row batch to f_dist_sparse (one lane per row)
 template <int KIND> struct OpSparse {
     static constexpr bool kSparse = true, mfma_split_ok = false, sorted_array_ok = false, kFloatAcc = false;
+    static constexpr int query_minw = 0;
     static constexpr int kind = KIND;
     typedef float acc_t;
     static __device__ __forceinline__ void init(acc_t &a) { a = 0.0f; }
