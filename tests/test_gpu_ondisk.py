@@ -483,3 +483,25 @@ def test_reference_016_concurrent_inserts_into_an_empty_index():
     assert len(set(t[0, :cnt[0]].tolist())) == cnt[0]
     ix.close()
     e.close()
+
+
+def test_ondisk_insert_at_m_above_32_needs_the_device_kernels():
+    """Lists of more than 64 slots are served by the device kernels only (the lock-step pair groups stop at 64 rows): with hx_index_set_fused(0) the call is refused,
+    with the kernels back on it goes through."""
+    rng = np.random.default_rng(33)
+    n, dim, m, efc = 120, 4, 33, 66
+    rows = make_rows(hx.F32, n, dim, rng)
+    e = hx.Engine(hx.F32, hx.L2SQ, dim, n)
+    e.append(rows)
+    ix = hx.Index(e, m, efc)
+    levels = hx.draw_levels(n, m, seed=2)
+    ix.set_fused(False)
+    with pytest.raises(hx.HxError) as ei:
+        ix.insert_ondisk(0, levels[:10], batch=1)
+    assert "m > 32" in str(ei.value)
+    assert ix.size == 0
+    ix.set_fused(True)
+    ix.insert_ondisk(0, levels, batch=7)
+    assert ix.size == n
+    ix.close()
+    e.close()
